@@ -1,0 +1,711 @@
+// C-ABI of the MI355X-native ICM sweep (include/icmslam.h): handle, HBM buffers, sweep
+// orchestration.  All device work goes to one HIP stream; the only host round trips per
+// sweep are two small counter reads (entry / new-landmark counts) and the raw-map download
+// for the host-side Mapa.filtrar.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/icmslam.h"
+#include "icm_host.hpp"
+#include "icm_kernels.hip"
+
+using namespace icm;
+
+namespace {
+
+std::string g_create_err;
+
+enum KernelId {
+    KID_PREFILTER = 0, KID_SCAN, KID_ASSOCIATE, KID_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_LOCAL,
+    KID_STATS_PREFIX, KID_LM_CHAIN, KID_BEAM_TARGETS, KID_SOLVE, KID_COUNT
+};
+const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_exscan_i32", "k_associate", "k_group", "k_compact",
+                                       "radix_sort_pairs", "k_lm_bounds", "k_lm_local", "k_stats_prefix",
+                                       "k_lm_chain", "k_beam_targets", "k_solve"};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct icm_handle {
+    icm_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // sequence
+    int64_t T = 0, B = 0, t_begin = 0, nloc = 0;
+    bool uploaded = false, prefiltered = false, have_state = false;
+    DevBuf<double> ranges, cosb, sinb, odo, u;
+    DevBuf<int> nkept, boff, bk;
+    DevBuf<double> bd, bx, by;
+    std::vector<int> h_boff;
+    int64_t nnz = 0;
+
+    // state
+    DevBuf<double> x_own, x0;
+    double* x = nullptr;  // (T,3): x_own or a bound external buffer
+    std::vector<double> h_map;  // current mapa_viejo (2,K) row-major
+    int64_t K = 0, lact = 0;
+    std::vector<double> h_counts;  // cant_obs_i after the last filtrar (L)
+    bool scan0_empty = false;
+
+    // association grid
+    Grid grid;
+    DevBuf<int> g_cell, g_id;
+    DevBuf<double> g_lx, g_ly, mapx, mapy;
+
+    // per-sweep
+    DevBuf<int> label, bloc, st_label, st_k, nent, isnew, ent_off, new_rank, e_val, e_k, sval, lm_off, flags;
+    DevBuf<unsigned> e_key, skey;
+    DevBuf<double> st_sx, st_sy, e_sx, e_sy, tgt_x, tgt_y, btx, bty;
+    DevBuf<double> stats_own, off_sx, off_sy, off_n, y_raw, cnt_raw, diag;
+    DevBuf<unsigned char> sort_tmp;
+    double* stats_all = nullptr;
+    int rank = 0, world = 1;
+    int64_t E = 0, n_new_loc = 0, lact_raw = 0;
+    int lact0 = 0;
+    bool brute = false;
+    int *pin_i = nullptr;
+    double* pin_d = nullptr;  // pinned staging: raw map download (3L)
+    std::vector<double> h_yraw, h_cntraw;
+
+    // timing
+    bool timing = false;
+    double k_ms[KID_COUNT] = {0};
+    int64_t k_n[KID_COUNT] = {0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define HIPCHK(h, call)                                                                             \
+    do {                                                                                            \
+        hipError_t e__ = (call);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                          \
+            return ICM_ERR_HIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+
+#define FAIL(h, code, msg)  \
+    do {                    \
+        (h)->err = (msg);   \
+        return (code);      \
+    } while (0)
+
+// Launch bracket: with timing on, events around the launch and an accumulate (serialises
+// the stream; used only for the per-kernel timing pass).
+#define TIMED(h, kid, stmt)                                                    \
+    do {                                                                       \
+        if ((h)->timing) (void)hipEventRecord((h)->ev0, (h)->stream);          \
+        stmt;                                                                  \
+        if ((h)->timing) {                                                     \
+            (void)hipEventRecord((h)->ev1, (h)->stream);                       \
+            (void)hipEventSynchronize((h)->ev1);                               \
+            float ms__ = 0.f;                                                  \
+            (void)hipEventElapsedTime(&ms__, (h)->ev0, (h)->ev1);              \
+            (h)->k_ms[kid] += ms__;                                            \
+            (h)->k_n[kid] += 1;                                                \
+        }                                                                      \
+    } while (0)
+
+static inline int nblocks_waves(int64_t nwaves) { return (int)((nwaves + kWavesPerBlock - 1) / kWavesPerBlock); }
+static inline int nblocks_threads(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+extern "C" {
+
+const char* icm_version(void) { return "icmslam-hip 0.1 (gfx950)"; }
+
+const char* icm_last_error(const icm_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int icm_create(const icm_config* cfg, int device, icm_handle** out) {
+    if (!cfg || !out) {
+        g_create_err = "icm_create: null argument";
+        return ICM_ERR_ARG;
+    }
+    *out = nullptr;
+    if (cfg->L <= 0 || cfg->L > (1 << 30)) {
+        g_create_err = "icm_create: L out of range";
+        return ICM_ERR_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("icm_create: no HIP device (") + hipGetErrorString(e) +
+                       "); this library has no CPU fallback";
+        return ICM_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_err = "icm_create: device index out of range";
+        return ICM_ERR_ARG;
+    }
+    icm_handle* h = new icm_handle();
+    h->cfg = *cfg;
+    h->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_i), 64 * sizeof(int))) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_d), (size_t)(3 * cfg->L + 16) * sizeof(double))) != hipSuccess) {
+        g_create_err = std::string("icm_create: ") + hipGetErrorString(e);
+        delete h;
+        return ICM_ERR_HIP;
+    }
+    h->own_stream = true;
+    h->h_counts.assign((size_t)cfg->L, 0.0);
+    *out = h;
+    return ICM_OK;
+}
+
+int icm_destroy(icm_handle* h) {
+    if (!h) return ICM_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf<double>* dd[] = {&h->ranges, &h->cosb, &h->sinb, &h->odo, &h->u, &h->bd, &h->bx, &h->by, &h->x_own, &h->x0,
+                            &h->g_lx, &h->g_ly, &h->mapx, &h->mapy, &h->st_sx, &h->st_sy, &h->e_sx, &h->e_sy, &h->tgt_x,
+                            &h->tgt_y, &h->btx, &h->bty, &h->stats_own, &h->off_sx, &h->off_sy, &h->off_n, &h->y_raw,
+                            &h->cnt_raw, &h->diag};
+    for (auto* b : dd) b->release();
+    DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->g_id, &h->label, &h->bloc, &h->st_label, &h->st_k,
+                         &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags};
+    for (auto* b : di) b->release();
+    h->e_key.release();
+    h->skey.release();
+    h->sort_tmp.release();
+    if (h->pin_i) (void)hipHostFree(h->pin_i);
+    if (h->pin_d) (void)hipHostFree(h->pin_d);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return ICM_OK;
+}
+
+int icm_set_stream(icm_handle* h, void* s) {
+    if (!h) return ICM_ERR_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = reinterpret_cast<hipStream_t>(s);
+    h->own_stream = false;
+    return ICM_OK;
+}
+
+int icm_upload(icm_handle* h, const double* ranges, const double* odo, const double* u, const double* cosb,
+               const double* sinb, int64_t T, int64_t B, int64_t t_begin, int64_t t_end) {
+    if (!h) return ICM_ERR_ARG;
+    if (!ranges || !odo || !u || !cosb || !sinb) FAIL(h, ICM_ERR_ARG, "icm_upload: null pointer");
+    if (T < 2 || B < 1 || t_begin < 0 || t_end > T || t_begin >= t_end) FAIL(h, ICM_ERR_ARG, "icm_upload: bad T/B/shard");
+    if (T > (1 << 30) || B > 8192 || (t_end - t_begin) * B > (int64_t)2000000000) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_upload: sequence too large for 32-bit beam indices");
+    HIPCHK(h, hipSetDevice(h->device));
+    h->T = T; h->B = B; h->t_begin = t_begin; h->nloc = t_end - t_begin;
+    const size_t nr = (size_t)h->nloc * (size_t)B;
+    HIPCHK(h, h->ranges.reserve(nr));
+    HIPCHK(h, h->cosb.reserve((size_t)B));
+    HIPCHK(h, h->sinb.reserve((size_t)B));
+    HIPCHK(h, h->odo.reserve(3 * (size_t)T));
+    HIPCHK(h, h->u.reserve(2 * (size_t)T));
+    HIPCHK(h, hipMemcpyAsync(h->ranges.p, ranges, nr * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->cosb.p, cosb, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->sinb.p, sinb, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->odo.p, odo, 3 * (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->u.p, u, 2 * (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->uploaded = true;
+    h->prefiltered = false;
+    h->have_state = false;
+    return ICM_OK;
+}
+
+int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->uploaded) FAIL(h, ICM_ERR_ARG, "icm_prefilter: call icm_upload first");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nloc = (int)h->nloc, B = (int)h->B;
+    HIPCHK(h, h->nkept.reserve((size_t)nloc + 1));
+    HIPCHK(h, h->boff.reserve((size_t)nloc + 1));
+    const size_t lds = (size_t)kWavesPerBlock * (size_t)B * (3 * sizeof(double) + sizeof(int));
+    if (lds > 160 * 1024) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_prefilter: too many beams per scan for the LDS staging");
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prefilter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prefilter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nb = nblocks_waves(nloc);
+    TIMED(h, KID_PREFILTER, (k_prefilter<false><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, h->nkept.p, nullptr, nullptr, nullptr, nullptr, nullptr)));
+    TIMED(h, KID_SCAN, (k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->nkept.p, h->boff.p, nloc)));
+    h->h_boff.assign((size_t)nloc + 1, 0);
+    HIPCHK(h, hipMemcpyAsync(h->h_boff.data(), h->boff.p, ((size_t)nloc + 1) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->nnz = h->h_boff[(size_t)nloc];
+    const size_t nz = (size_t)std::max<int64_t>(h->nnz, 1);
+    HIPCHK(h, h->bk.reserve(nz));
+    HIPCHK(h, h->bd.reserve(nz));
+    HIPCHK(h, h->bx.reserve(nz));
+    HIPCHK(h, h->by.reserve(nz));
+    TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p)));
+    // per-sweep buffers sized by the kept beams
+    HIPCHK(h, h->label.reserve(nz)); HIPCHK(h, h->bloc.reserve(nz)); HIPCHK(h, h->st_label.reserve(nz));
+    HIPCHK(h, h->st_k.reserve(nz)); HIPCHK(h, h->st_sx.reserve(nz)); HIPCHK(h, h->st_sy.reserve(nz));
+    HIPCHK(h, h->btx.reserve(nz)); HIPCHK(h, h->bty.reserve(nz));
+    HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz));
+    HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_sx.reserve(nz));
+    HIPCHK(h, h->e_sy.reserve(nz)); HIPCHK(h, h->tgt_x.reserve(nz)); HIPCHK(h, h->tgt_y.reserve(nz));
+    HIPCHK(h, h->nent.reserve((size_t)nloc + 1)); HIPCHK(h, h->isnew.reserve((size_t)nloc + 1));
+    HIPCHK(h, h->ent_off.reserve((size_t)nloc + 1)); HIPCHK(h, h->new_rank.reserve((size_t)nloc + 1));
+    const size_t L = (size_t)h->cfg.L;
+    HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(8));
+    HIPCHK(h, h->stats_own.reserve(3 * L + 8)); HIPCHK(h, h->off_sx.reserve(L)); HIPCHK(h, h->off_sy.reserve(L));
+    HIPCHK(h, h->off_n.reserve(L)); HIPCHK(h, h->y_raw.reserve(2 * L)); HIPCHK(h, h->cnt_raw.reserve(L));
+    HIPCHK(h, h->g_lx.reserve(L)); HIPCHK(h, h->g_ly.reserve(L)); HIPCHK(h, h->g_id.reserve(L));
+    HIPCHK(h, h->mapx.reserve(L)); HIPCHK(h, h->mapy.reserve(L));
+    HIPCHK(h, h->g_cell.reserve(4 * L + 1024 + 2));
+    size_t tmp_bytes = 0;
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, nz, 0, 32, h->stream));
+    HIPCHK(h, h->sort_tmp.reserve(tmp_bytes + 256));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->prefiltered = true;
+    if (nnz_out) *nnz_out = h->nnz;
+    return ICM_OK;
+}
+
+int icm_get_kept(icm_handle* h, int64_t* offsets, int32_t* beam_index, double* d, double* bx, double* by) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->prefiltered) FAIL(h, ICM_ERR_ARG, "icm_get_kept: call icm_prefilter first");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (offsets)
+        for (size_t i = 0; i <= (size_t)h->nloc; ++i) offsets[i] = h->h_boff[i];
+    const size_t nz = (size_t)h->nnz;
+    if (nz) {
+        if (beam_index) HIPCHK(h, hipMemcpy(beam_index, h->bk.p, nz * sizeof(int), hipMemcpyDeviceToHost));
+        if (d) HIPCHK(h, hipMemcpy(d, h->bd.p, nz * sizeof(double), hipMemcpyDeviceToHost));
+        if (bx) HIPCHK(h, hipMemcpy(bx, h->bx.p, nz * sizeof(double), hipMemcpyDeviceToHost));
+        if (by) HIPCHK(h, hipMemcpy(by, h->by.p, nz * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return ICM_OK;
+}
+
+// Upload the current mapa_viejo and its search grid (per sweep; K <= L landmarks).
+static int upload_map(icm_handle* h) {
+    // columns the reference can match against: mapa_referencia[:, :Lact] (numpy clamps the
+    // slice to the K columns that exist), scripts/ICM_SLAM_tools.py:169
+    const int64_t km = std::min(h->K, h->lact);
+    const double* mx = h->h_map.data();
+    const double* my = h->h_map.data() + h->K;
+    build_grid(mx, my, km, h->cfg.dist_thr, h->grid);
+    const Grid& g = h->grid;
+    HIPCHK(h, h->g_cell.reserve(g.cell_start.size()));
+    HIPCHK(h, hipMemcpyAsync(h->g_cell.p, g.cell_start.data(), g.cell_start.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (km > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->g_lx.p, g.lx.data(), (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->g_ly.p, g.ly.data(), (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->g_id.p, g.id.data(), (size_t)km * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->mapx.p, mx, (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->mapy.p, my, (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors are reused
+    return ICM_OK;
+}
+
+int icm_set_state(icm_handle* h, const double* x, const double* x0, const double* map_in, int64_t K, int64_t lact_in) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->prefiltered) FAIL(h, ICM_ERR_ARG, "icm_set_state: call icm_upload + icm_prefilter first");
+    if (!x || !x0 || (K > 0 && !map_in)) FAIL(h, ICM_ERR_ARG, "icm_set_state: null pointer");
+    if (K < 0 || K > h->cfg.L || lact_in < 0) FAIL(h, ICM_ERR_ARG, "icm_set_state: K outside [0, L]");
+    if (lact_in == 0) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_set_state: landmarks_actuales == 0 (first-scan clustering branch, scripts/ICM_SLAM_tools.py:160-165) is not part of the sweep");
+    if (lact_in < K) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_set_state: landmarks_actuales < columns of mapa_viejo is not supported");
+    if (lact_in > h->cfg.L) FAIL(h, ICM_ERR_INDEX, "icm_set_state: landmarks_actuales > L");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t T = (size_t)h->T;
+    if (!h->x) {
+        HIPCHK(h, h->x_own.reserve(3 * T));
+        h->x = h->x_own.p;
+    }
+    HIPCHK(h, h->x0.reserve(3));
+    std::vector<double> xt(3 * T);
+    for (size_t t = 0; t < T; ++t) {
+        xt[3 * t] = x[t];
+        xt[3 * t + 1] = x[T + t];
+        xt[3 * t + 2] = x[2 * T + t];
+    }
+    HIPCHK(h, hipMemcpyAsync(h->x, xt.data(), 3 * T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->x0.p, x0, 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->h_map.assign(map_in, map_in + 2 * K);
+    h->K = K;
+    h->lact = lact_in;
+    int rc = upload_map(h);
+    if (rc) return rc;
+    h->have_state = true;
+    return ICM_OK;
+}
+
+int64_t icm_stats_stride(const icm_handle* h) { return h ? 3 * h->cfg.L + 8 : 0; }
+
+int icm_bind_exchange(icm_handle* h, void* stats_all_dev, int rank, int world) {
+    if (!h) return ICM_ERR_ARG;
+    if (world < 1 || rank < 0 || rank >= world) FAIL(h, ICM_ERR_ARG, "icm_bind_exchange: bad rank/world");
+    if (world > 1 && !stats_all_dev) FAIL(h, ICM_ERR_ARG, "icm_bind_exchange: null exchange buffer");
+    h->stats_all = reinterpret_cast<double*>(stats_all_dev);
+    h->rank = rank;
+    h->world = world;
+    return ICM_OK;
+}
+
+void* icm_pose_buffer(icm_handle* h) {
+    if (!h) return nullptr;
+    if (!h->x) {
+        (void)hipSetDevice(h->device);
+        if (h->x_own.reserve(3 * (size_t)h->T) != hipSuccess) return nullptr;
+        h->x = h->x_own.p;
+    }
+    return h->x;
+}
+
+__global__ void k_set_header(double* stats, int L, double n_new, double flags) {
+    stats[3 * (size_t)L] = n_new;
+    stats[3 * (size_t)L + 1] = flags;
+}
+
+// Phase A + local statistics.
+int icm_sweep_local(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_local: no state (icm_set_state)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nloc = (int)h->nloc, L = (int)h->cfg.L;
+    // pose 0 without kept beams: the reference returns its inputs untouched
+    // (scripts/ICM_ROS.py:133-135).  Every rank sees the same scan 0 only if it owns it; the
+    // host side checks this before sharding.
+    h->scan0_empty = (h->t_begin == 0 && h->h_boff[1] == h->h_boff[0]);
+    if (h->scan0_empty) return ICM_OK;
+    // a no-beam last pose indexes x[:, T] in the reference (IndexError, scripts/ICM_ROS.py:144)
+    if (h->t_begin + h->nloc == h->T && h->h_boff[(size_t)nloc] == h->h_boff[(size_t)nloc - 1])
+        FAIL(h, ICM_ERR_INDEX, "sweep: the last pose has no kept beams (the reference raises IndexError at scripts/ICM_ROS.py:144)");
+    h->lact0 = (int)h->lact;
+    const int km = (int)std::min(h->K, h->lact);
+    const int nbw = nblocks_waves(nloc);
+    HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
+    if (h->brute) {
+        TIMED(h, KID_ASSOCIATE, (k_associate_brute<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->mapx.p, h->mapy.p, km, h->cfg.dist_thr, h->label.p)));
+    } else {
+        GridView gv{h->grid.gx0, h->grid.gy0, h->grid.inv, h->grid.nx, h->grid.ny, h->g_cell.p, h->g_lx.p, h->g_ly.p, h->g_id.p};
+        TIMED(h, KID_ASSOCIATE, (k_associate<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->label.p)));
+    }
+    TIMED(h, KID_GROUP, (k_group<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->label.p, h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p)));
+    TIMED(h, KID_SCAN, (k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->nent.p, h->ent_off.p, nloc)));
+    TIMED(h, KID_SCAN, (k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->isnew.p, h->new_rank.p, nloc)));
+    HIPCHK(h, hipMemcpyAsync(h->pin_i, h->ent_off.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->pin_i + 1, h->new_rank.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->E = h->pin_i[0];
+    h->n_new_loc = h->pin_i[1];
+    if (h->pin_i[2]) FAIL(h, ICM_ERR_CAPACITY, "sweep: a scan touched more than 256 distinct landmarks");
+    if ((int64_t)h->lact0 + h->n_new_loc > L)
+        FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
+    const int nlab = h->lact0 + (int)h->n_new_loc;
+    const int E = (int)h->E;
+    TIMED(h, KID_COMPACT, (k_compact<<<nbw, kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->e_key.p, h->e_val.p, h->e_k.p, h->e_sx.p, h->e_sy.p)));
+    int bits = 1;
+    while ((1ll << bits) < (int64_t)nlab + 1) ++bits;
+    size_t tmp_bytes = h->sort_tmp.cap;
+    if (E > 0)
+        TIMED(h, KID_SORT, HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp.p, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, (size_t)E, 0, bits, h->stream)));
+    TIMED(h, KID_LM_BOUNDS, (k_lm_bounds<<<nblocks_threads(nlab + 1), kBlock, 0, h->stream>>>(h->skey.p, E, nlab, h->lm_off.p)));
+    double* stats_mine = h->world > 1 ? h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h) : h->stats_own.p;
+    TIMED(h, KID_LM_LOCAL, (k_lm_local<<<nblocks_threads(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_k.p, h->e_sx.p, h->e_sy.p, stats_mine)));
+    k_set_header<<<1, 1, 0, h->stream>>>(stats_mine, L, (double)h->n_new_loc, 0.0);
+    HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
+// After the (optional) all-gather: offsets, raw map, targets.
+int icm_sweep_targets(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_targets: no state");
+    if (h->scan0_empty) return ICM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nloc = (int)h->nloc, L = (int)h->cfg.L;
+    const int nlab = h->lact0 + (int)h->n_new_loc;
+    const double* all = h->world > 1 ? h->stats_all : h->stats_own.p;
+    TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
+    TIMED(h, KID_LM_CHAIN, (k_lm_chain<<<nblocks_threads(nlab), kBlock, 0, h->stream>>>(nlab, h->lm_off.p, h->sval.p, h->e_k.p, h->e_sx.p, h->e_sy.p, h->off_sx.p, h->off_sy.p, h->off_n.p, h->tgt_x.p, h->tgt_y.p)));
+    TIMED(h, KID_BEAM_TARGETS, (k_beam_targets<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->bloc.p, h->tgt_x.p, h->tgt_y.p, h->btx.p, h->bty.p)));
+    HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
+int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: no state");
+    if (h->scan0_empty) return ICM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    SolveArgs a;
+    a.x = h->x; a.x0 = h->x0.p; a.odo = h->odo.p; a.u = h->u.p;
+    a.T = (int)h->T; a.t_begin = (int)h->t_begin; a.nloc = (int)h->nloc;
+    a.boff = h->boff.p; a.bx = h->bx.p; a.by = h->by.p; a.btx = h->btx.p; a.bty = h->bty.p;
+    a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
+    a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
+    a.diag = h->diag.p;
+    if (schedule == ICM_SCHEDULE_SEQUENTIAL) {
+        if (h->world != 1) FAIL(h, ICM_ERR_UNSUPPORTED, "the sequential (reference-order) schedule is one dependent chain and cannot be sharded");
+        TIMED(h, KID_SOLVE, (k_solve_sequential<<<1, kWave, 0, h->stream>>>(a)));
+    } else if (schedule == ICM_SCHEDULE_REDBLACK) {
+        const int nw = (int)(h->nloc / 2 + 1);
+        if (colour == 1 || colour < 0) TIMED(h, KID_SOLVE, (k_solve_colour<<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, 1)));
+        if (colour == 0 || colour < 0) TIMED(h, KID_SOLVE, (k_solve_colour<<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, 0)));
+    } else {
+        FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: unknown schedule");
+    }
+    HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
+int icm_sweep_finish(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_finish: no state");
+    if (h->scan0_empty) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return ICM_OK;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t L = (size_t)h->cfg.L;
+    // total number of landmarks created this sweep, over all ranks
+    int64_t n_new = h->n_new_loc;
+    if (h->world > 1) {
+        n_new = 0;
+        for (int r = 0; r < h->world; ++r) {
+            double v = 0.0;
+            HIPCHK(h, hipMemcpyAsync(&v, h->stats_all + (size_t)r * (size_t)icm_stats_stride(h) + 3 * L, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            n_new += (int64_t)v;
+        }
+    }
+    h->lact_raw = h->lact0 + n_new;
+    if (h->lact_raw > (int64_t)L) FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L");
+    HIPCHK(h, hipMemcpyAsync(h->pin_d, h->y_raw.p, 2 * L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->pin_d + 2 * L, h->cnt_raw.p, L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->h_yraw.assign(h->pin_d, h->pin_d + 2 * L);
+    h->h_cntraw.assign(h->pin_d + 2 * L, h->pin_d + 3 * L);
+    std::vector<double> yo(2 * L), co(L);
+    int64_t lact_new = 0;
+    int rc = filtrar_host(h->cfg, h->h_yraw.data(), h->h_cntraw.data(), h->lact_raw, yo.data(), co.data(), &lact_new, h->err);
+    if (rc) return rc;
+    // the refined map becomes the next mapa_viejo (scripts/ICM_ROS.py:311)
+    h->K = lact_new;
+    h->lact = lact_new;
+    h->h_map.resize(2 * (size_t)lact_new);
+    for (int64_t i = 0; i < lact_new; ++i) {
+        h->h_map[(size_t)i] = yo[(size_t)i];
+        h->h_map[(size_t)(lact_new + i)] = yo[L + (size_t)i];
+    }
+    h->h_counts = co;
+    return upload_map(h);
+}
+
+int icm_sweep_device(icm_handle* h, int schedule) {
+    int rc;
+    if ((rc = icm_sweep_local(h))) return rc;
+    if ((rc = icm_sweep_targets(h))) return rc;
+    if ((rc = icm_sweep_solve(h, schedule, -1))) return rc;
+    return icm_sweep_finish(h);
+}
+
+int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out, int64_t* K_out) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_get_state: no state");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t T = (size_t)h->T, L = (size_t)h->cfg.L;
+    if (x) {
+        std::vector<double> xt(3 * T);
+        HIPCHK(h, hipMemcpyAsync(xt.data(), h->x, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (size_t t = 0; t < T; ++t) {
+            x[t] = xt[3 * t];
+            x[T + t] = xt[3 * t + 1];
+            x[2 * T + t] = xt[3 * t + 2];
+        }
+    }
+    if (map_out) {
+        std::fill(map_out, map_out + 2 * L, 0.0);
+        for (int64_t i = 0; i < h->K; ++i) {
+            map_out[(size_t)i] = h->h_map[(size_t)i];
+            map_out[L + (size_t)i] = h->h_map[(size_t)(h->K + i)];
+        }
+    }
+    if (counts_out) std::copy(h->h_counts.begin(), h->h_counts.end(), counts_out);
+    if (K_out) *K_out = h->scan0_empty ? -1 : h->lact;
+    return ICM_OK;
+}
+
+int icm_sweep(icm_handle* h, double* x, const double* x0, const double* map_in, int64_t K, int64_t lact_in,
+              int schedule, double* map_out, double* counts_out, int64_t* K_out) {
+    int rc;
+    if ((rc = icm_set_state(h, x, x0, map_in, K, lact_in))) return rc;
+    if ((rc = icm_sweep_device(h, schedule))) return rc;
+    if (h->scan0_empty) {
+        if (K_out) *K_out = -1;
+        return ICM_OK;
+    }
+    return icm_get_state(h, x, map_out, counts_out, K_out);
+}
+
+int icm_get_association(icm_handle* h, int32_t* labels, double* target_x, double* target_y) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_get_association: no sweep has run");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t nz = (size_t)h->nnz;
+    if (!nz) return ICM_OK;
+    if (labels) {
+        HIPCHK(h, hipMemcpy(labels, h->label.p, nz * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<int> nr((size_t)h->nloc + 1);
+        HIPCHK(h, hipMemcpy(nr.data(), h->new_rank.p, nr.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < (size_t)h->nloc; ++t)
+            for (int j = h->h_boff[t]; j < h->h_boff[t + 1]; ++j)
+                if (labels[j] < 0) labels[j] = h->lact0 + nr[t];
+    }
+    if (target_x) HIPCHK(h, hipMemcpy(target_x, h->btx.p, nz * sizeof(double), hipMemcpyDeviceToHost));
+    if (target_y) HIPCHK(h, hipMemcpy(target_y, h->bty.p, nz * sizeof(double), hipMemcpyDeviceToHost));
+    return ICM_OK;
+}
+
+int icm_get_raw_map(icm_handle* h, double* y, double* counts, int64_t* lact) {
+    if (!h) return ICM_ERR_ARG;
+    if (h->h_yraw.empty()) FAIL(h, ICM_ERR_ARG, "icm_get_raw_map: no sweep has finished");
+    if (y) std::copy(h->h_yraw.begin(), h->h_yraw.end(), y);
+    if (counts) std::copy(h->h_cntraw.begin(), h->h_cntraw.end(), counts);
+    if (lact) *lact = h->lact_raw;
+    return ICM_OK;
+}
+
+static int run_one(icm_handle* h, int energy_only, int two_sided, const double* x, const double* x_ant,
+                   const double* x_pos, const double* u, const double* odo, int odo_cols, const double* bx,
+                   const double* by, const double* tx, const double* ty, int64_t n, double* out) {
+    if (!h) return ICM_ERR_ARG;
+    if (!x_ant || !u || !odo || !out || (n > 0 && (!bx || !by || !tx || !ty))) FAIL(h, ICM_ERR_ARG, "solve_one: null pointer");
+    if (two_sided && (!x_pos || odo_cols != 3)) FAIL(h, ICM_ERR_ARG, "solve_one: two-sided needs x_pos and odo (3,3)");
+    if (!two_sided && odo_cols != 2 && odo_cols != 3) FAIL(h, ICM_ERR_ARG, "solve_one: odo must be (3,2) or (3,3)");
+    if (n < 0 || n > (1 << 24)) FAIL(h, ICM_ERR_ARG, "solve_one: bad n");
+    HIPCHK(h, hipSetDevice(h->device));
+    double p[22] = {0};
+    if (x) std::memcpy(p, x, 3 * sizeof(double));
+    std::memcpy(p + 3, x_ant, 3 * sizeof(double));
+    if (two_sided) std::memcpy(p + 6, x_pos, 3 * sizeof(double));
+    // u is (2,2) row-major = u[:, t-1:t+1] (two-sided) or (2,1) = u[:, t-1]
+    const int uc = two_sided ? 2 : 1;
+    p[9] = u[0]; p[10] = u[uc];
+    if (two_sided) { p[11] = u[1]; p[12] = u[uc + 1]; }
+    for (int r = 0; r < 3; ++r) {
+        p[13 + r] = odo[r * odo_cols];
+        p[16 + r] = odo[r * odo_cols + 1];
+        if (two_sided) p[19 + r] = odo[r * odo_cols + 2];
+    }
+    DevBuf<double> buf;
+    const size_t nn = (size_t)n;
+    HIPCHK(h, buf.reserve(22 + 4 * nn + 6));
+    HIPCHK(h, hipMemcpy(buf.p, p, 22 * sizeof(double), hipMemcpyHostToDevice));
+    if (nn) {
+        HIPCHK(h, hipMemcpy(buf.p + 22, bx, nn * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(buf.p + 22 + nn, by, nn * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(buf.p + 22 + 2 * nn, tx, nn * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(buf.p + 22 + 3 * nn, ty, nn * sizeof(double), hipMemcpyHostToDevice));
+    }
+    OneArgs a;
+    a.two_sided = two_sided; a.energy_only = energy_only; a.n = (int)n;
+    a.p = buf.p; a.bx = buf.p + 22; a.by = buf.p + 22 + nn; a.tx = buf.p + 22 + 2 * nn; a.ty = buf.p + 22 + 3 * nn;
+    a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
+    a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
+    a.out = buf.p + 22 + 4 * nn;
+    k_solve_one<<<1, kWave, 0, h->stream>>>(a);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double o[6];
+    HIPCHK(h, hipMemcpy(o, a.out, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    buf.release();
+    if (energy_only) out[0] = o[3]; else std::memcpy(out, o, 6 * sizeof(double));
+    return ICM_OK;
+}
+
+int icm_solve_one(icm_handle* h, int two_sided, const double* x_ant, const double* x_pos, const double* u,
+                  const double* odo, int odo_cols, const double* bx, const double* by, const double* tx,
+                  const double* ty, int64_t n, double* out) {
+    return run_one(h, 0, two_sided, nullptr, x_ant, x_pos, u, odo, odo_cols, bx, by, tx, ty, n, out);
+}
+
+int icm_energy_one(icm_handle* h, int two_sided, const double* x, const double* x_ant, const double* x_pos,
+                   const double* u, const double* odo, int odo_cols, const double* bx, const double* by,
+                   const double* tx, const double* ty, int64_t n, double* out) {
+    if (h && !x) FAIL(h, ICM_ERR_ARG, "icm_energy_one: null x");
+    return run_one(h, 1, two_sided, x, x_ant, x_pos, u, odo, odo_cols, bx, by, tx, ty, n, out);
+}
+
+int icm_filtrar(const icm_config* cfg, const double* y, const double* counts, int64_t lact, double* y_out,
+                double* counts_out, int64_t* lact_out) {
+    if (!cfg || !y || !counts || !y_out || !counts_out || !lact_out) {
+        g_create_err = "icm_filtrar: null argument";
+        return ICM_ERR_ARG;
+    }
+    return filtrar_host(*cfg, y, counts, lact, y_out, counts_out, lact_out, g_create_err);
+}
+
+int icm_enable_timing(icm_handle* h, int on) {
+    if (!h) return ICM_ERR_ARG;
+    h->timing = on != 0;
+    return ICM_OK;
+}
+int icm_reset_timing(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    for (int i = 0; i < KID_COUNT; ++i) {
+        h->k_ms[i] = 0.0;
+        h->k_n[i] = 0;
+    }
+    return ICM_OK;
+}
+int icm_kernel_count(const icm_handle*) { return KID_COUNT; }
+int icm_kernel_time(icm_handle* h, int idx, const char** name, double* ms, int64_t* launches) {
+    if (!h || idx < 0 || idx >= KID_COUNT) return ICM_ERR_ARG;
+    if (name) *name = kKernelNames[idx];
+    if (ms) *ms = h->k_ms[idx];
+    if (launches) *launches = h->k_n[idx];
+    return ICM_OK;
+}
+int icm_last_stats(const icm_handle* h, int64_t* out4) {
+    if (!h || !out4) return ICM_ERR_ARG;
+    out4[0] = h->nnz;
+    out4[1] = h->E;
+    out4[2] = h->n_new_loc;
+    out4[3] = h->lact_raw;
+    return ICM_OK;
+}
+
+// test hook: switch phase A to the brute-force (all landmarks, LDS-tiled) kernel
+int icm_set_brute_force(icm_handle* h, int on) {
+    if (!h) return ICM_ERR_ARG;
+    h->brute = on != 0;
+    return ICM_OK;
+}
+
+}  // extern "C"

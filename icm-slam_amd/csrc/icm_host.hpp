@@ -1,0 +1,30 @@
+// Host-side pieces of the sweep: Mapa.filtrar (prune/merge of the running map) and the
+// uniform grid over mapa_viejo that the association kernel searches.  Plain C++, no HIP.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/icmslam.h"
+
+namespace icm {
+
+// Uniform grid over the reference map for the gated nearest-landmark search.
+// Cell edge >= dist_thr, so every landmark within dist_thr of a point lies in the 3x3
+// cells around the point's cell.  Landmarks are stored sorted by cell (counting sort);
+// `id` keeps the original column index for the first-index tie-break of np.argmin.
+struct Grid {
+    double gx0 = 0, gy0 = 0, inv = 1;
+    int nx = 1, ny = 1;
+    std::vector<int> cell_start;  // nx*ny + 1
+    std::vector<double> lx, ly;   // sorted by cell
+    std::vector<int> id;
+};
+
+void build_grid(const double* map_x, const double* map_y, int64_t K, double dist_thr, Grid& g);
+
+// Mapa.filtrar, reference scripts/ICM_SLAM_tools.py:204-265.  y is (2,L) row-major.
+int filtrar_host(const icm_config& cfg, const double* y, const double* counts, int64_t lact,
+                 double* y_out, double* counts_out, int64_t* lact_out, std::string& err);
+
+}  // namespace icm

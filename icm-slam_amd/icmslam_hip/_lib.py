@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI in include/icmslam.h (libicmslam_hip.so).
+
+There is no CPU fallback: if the shared library has not been built (or no MI355X is
+present when a solver is created) the import / constructor fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libicmslam_hip.so")
+
+ICM_OK = 0
+ICM_ERR_ARG = -1
+ICM_ERR_HIP = -2
+ICM_ERR_INDEX = -3
+ICM_ERR_EMPTY_MAP = -4
+ICM_ERR_CAPACITY = -5
+ICM_ERR_UNSUPPORTED = -6
+SCHEDULES = {"sequential": 0, "redblack": 1}
+
+
+class IcmConfig(C.Structure):
+    _fields_ = [("deltat", C.c_double), ("Q", C.c_double * 2), ("R", C.c_double * 3),
+                ("cte_odom", C.c_double), ("cota", C.c_double), ("dist_thr", C.c_double),
+                ("rango_laser_max", C.c_double), ("L", C.c_int64)]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_H = C.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/icmslam.h
+SIGNATURES = {
+    "icm_create": (C.c_int, [C.POINTER(IcmConfig), C.c_int, C.POINTER(_H)]),
+    "icm_destroy": (C.c_int, [_H]),
+    "icm_last_error": (C.c_char_p, [_H]),
+    "icm_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "icm_upload": (C.c_int, [_H, _dp, _dp, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "icm_prefilter": (C.c_int, [_H, _lp]),
+    "icm_get_kept": (C.c_int, [_H, _lp, _ip, _dp, _dp, _dp]),
+    "icm_sweep": (C.c_int, [_H, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp, _lp]),
+    "icm_set_state": (C.c_int, [_H, _dp, _dp, _dp, C.c_int64, C.c_int64]),
+    "icm_sweep_device": (C.c_int, [_H, C.c_int]),
+    "icm_get_state": (C.c_int, [_H, _dp, _dp, _dp, _lp]),
+    "icm_stats_stride": (C.c_int64, [_H]),
+    "icm_bind_exchange": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    "icm_pose_buffer": (C.c_void_p, [_H]),
+    "icm_sweep_local": (C.c_int, [_H]),
+    "icm_sweep_targets": (C.c_int, [_H]),
+    "icm_sweep_solve": (C.c_int, [_H, C.c_int, C.c_int]),
+    "icm_sweep_finish": (C.c_int, [_H]),
+    "icm_get_association": (C.c_int, [_H, _ip, _dp, _dp]),
+    "icm_get_raw_map": (C.c_int, [_H, _dp, _dp, _lp]),
+    "icm_solve_one": (C.c_int, [_H, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp]),
+    "icm_energy_one": (C.c_int, [_H, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp]),
+    "icm_filtrar": (C.c_int, [C.POINTER(IcmConfig), _dp, _dp, C.c_int64, _dp, _dp, _lp]),
+    "icm_enable_timing": (C.c_int, [_H, C.c_int]),
+    "icm_reset_timing": (C.c_int, [_H]),
+    "icm_kernel_count": (C.c_int, [_H]),
+    "icm_kernel_time": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), _dp, _lp]),
+    "icm_last_stats": (C.c_int, [_H, _lp]),
+    "icm_set_brute_force": (C.c_int, [_H, C.c_int]),
+    "icm_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libicmslam_hip.so and declare every entry point.  Raises ImportError if the
+    library is missing -- build it with `python __graft_entry__.py` (or `make -C
+    icm-slam_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libicmslam_hip.so not found at %s: the HIP extension is not built and there is no "
+            "CPU fallback. Run `make -C icm-slam_amd/csrc` (hipcc, --offload-arch=gfx950)." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def lptr(a):
+    return a.ctypes.data_as(_lp) if a is not None else None

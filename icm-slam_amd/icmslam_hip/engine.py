@@ -1,0 +1,266 @@
+"""Host-side driver of the HIP sweep: owns one C-ABI handle (one GPU / rank).
+
+The arrays keep the reference's layouts: `mediciones` (B,T) beam-major, `odometria`
+(3,T), `u` (2,T), poses `x` (3,T), maps (2,K) (reference scripts/ICM_ROS.py:20-24,121).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import IcmConfig, SCHEDULES, dptr, iptr, lptr
+
+
+class IcmError(RuntimeError):
+    pass
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def bearing_tables(B, angle_increment=None):
+    """cos/sin of the beam bearings.  Default = the reference's hard-coded 1 degree per scan
+    row, index*pi/180 (reference scripts/ICM_SLAM_tools.py:44,51)."""
+    k = np.arange(B)
+    ang = k * np.pi / 180.0 if angle_increment is None else k * float(angle_increment)
+    return np.cos(ang), np.sin(ang), ang
+
+
+def make_c_config(config):
+    c = IcmConfig()
+    c.deltat = float(config.deltat)
+    c.Q[0], c.Q[1] = float(config.Q[0, 0]), float(config.Q[1, 1])
+    c.R[0], c.R[1], c.R[2] = float(config.R[0, 0]), float(config.R[1, 1]), float(config.R[2, 2])
+    c.cte_odom = float(config.cte_odom)
+    c.cota = float(config.cota)
+    c.dist_thr = float(config.dist_thr)
+    c.rango_laser_max = float(config.rango_laser_max)
+    c.L = int(config.L)
+    return c
+
+
+def filtrar_map(config, y, counts, lact):
+    """Mapa.filtrar through the C-ABI host routine (no GPU involved).
+    Returns (y_out (2,L), counts_out (L), lact_out)."""
+    lib = _lib.load()
+    cc = make_c_config(config)
+    L = int(config.L)
+    y = _f64(y)
+    counts = _f64(counts)
+    if y.shape != (2, L) or counts.shape != (L,):
+        raise ValueError("filtrar: map must be (2,L) and counts (L,)")
+    yo = np.zeros((2, L))
+    co = np.zeros(L)
+    lo = C.c_int64(0)
+    rc = lib.icm_filtrar(C.byref(cc), dptr(y), dptr(counts), int(lact), dptr(yo), dptr(co), C.byref(lo))
+    if rc:
+        _raise(rc, lib.icm_last_error(None).decode())
+    return yo, co, int(lo.value)
+
+
+def _raise(rc, msg):
+    if rc == _lib.ICM_ERR_INDEX:
+        raise IndexError(msg)
+    if rc == _lib.ICM_ERR_EMPTY_MAP:
+        raise ValueError(msg)
+    if rc == _lib.ICM_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == _lib.ICM_ERR_ARG:
+        raise ValueError(msg)
+    raise IcmError("icmslam_hip error %d: %s" % (rc, msg))
+
+
+class SweepEngine:
+    """One GPU worth of the offline ICM sweep."""
+
+    def __init__(self, config, device=0):
+        self.lib = _lib.load()
+        self.config = config
+        self.cconf = make_c_config(config)
+        self.L = int(config.L)
+        h = C.c_void_p()
+        rc = self.lib.icm_create(C.byref(self.cconf), int(device), C.byref(h))
+        if rc:
+            _raise(rc, self.lib.icm_last_error(None).decode())
+        self.h = h
+        self.T = self.B = self.nloc = 0
+        self.t_begin = 0
+        self.nnz = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.icm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            _raise(rc, self.lib.icm_last_error(self.h).decode())
+
+    # ---- sequence --------------------------------------------------------------------
+    def upload(self, mediciones, odometria, u, t_begin=0, t_end=None, pose_major=False):
+        """Upload the sequence (or this rank's pose shard of the scans) and run the scan
+        pre-filter once.  `mediciones` is (B,T) like the reference unless pose_major."""
+        odometria = _f64(odometria)
+        u = _f64(u)
+        T = odometria.shape[1]
+        t_end = T if t_end is None else int(t_end)
+        if pose_major:
+            scans = _f64(mediciones)
+            B = scans.shape[1]
+            if scans.shape[0] != t_end - t_begin:
+                raise ValueError("pose-major scans must hold exactly the shard's poses")
+        else:
+            m = np.asarray(mediciones, dtype=np.float64)
+            B = m.shape[0]
+            if m.shape[1] != T:
+                raise ValueError("mediciones must be (B,T)")
+            scans = np.ascontiguousarray(m[:, t_begin:t_end].T)
+        if odometria.shape != (3, T) or u.shape != (2, T):
+            raise ValueError("odometria must be (3,T) and u (2,T)")
+        cosb, sinb, _ = bearing_tables(B, getattr(self.config, "angle_increment", None))
+        self._chk(self.lib.icm_upload(self.h, dptr(scans), dptr(odometria), dptr(u), dptr(_f64(cosb)),
+                                      dptr(_f64(sinb)), T, B, int(t_begin), t_end))
+        nnz = C.c_int64(0)
+        self._chk(self.lib.icm_prefilter(self.h, C.byref(nnz)))
+        self.T, self.B, self.t_begin, self.nloc, self.nnz = T, B, int(t_begin), t_end - int(t_begin), int(nnz.value)
+        return self.nnz
+
+    def kept_beams(self):
+        """(offsets[nloc+1], beam_index, d, bx, by) of the cached filtrar_z output."""
+        off = np.zeros(self.nloc + 1, dtype=np.int64)
+        n = max(self.nnz, 1)
+        bk = np.zeros(n, dtype=np.int32)
+        d, bx, by = np.zeros(n), np.zeros(n), np.zeros(n)
+        self._chk(self.lib.icm_get_kept(self.h, lptr(off), iptr(bk), dptr(d), dptr(bx), dptr(by)))
+        k = self.nnz
+        return off, bk[:k], d[:k], bx[:k], by[:k]
+
+    # ---- one sweep through host arrays -------------------------------------------------
+    def sweep(self, mapa_viejo, x, x0, lact, schedule="sequential"):
+        """iterations_process_offline.  x (3,T) float64 C-contiguous is updated IN PLACE.
+        Returns (map (2,L) zero padded, counts (L), K) or None if scan 0 has no beams."""
+        if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous and x.shape == (3, self.T)):
+            raise ValueError("x must be a C-contiguous float64 array of shape (3,T)")
+        mv = _f64(mapa_viejo)
+        K = mv.shape[1]
+        x0v = _f64(np.asarray(x0, dtype=np.float64).reshape(3))
+        mo = np.zeros((2, self.L))
+        co = np.zeros(self.L)
+        ko = C.c_int64(0)
+        self._chk(self.lib.icm_sweep(self.h, dptr(x), dptr(x0v), dptr(mv), K, int(lact), SCHEDULES[schedule],
+                                     dptr(mo), dptr(co), C.byref(ko)))
+        if ko.value < 0:
+            return None
+        return mo, co, int(ko.value)
+
+    # ---- device-resident sweeps --------------------------------------------------------
+    def set_state(self, mapa_viejo, x, x0, lact=None):
+        mv = _f64(mapa_viejo)
+        xx = _f64(x)
+        x0v = _f64(np.asarray(x0, dtype=np.float64).reshape(3))
+        lact = mv.shape[1] if lact is None else int(lact)
+        self._chk(self.lib.icm_set_state(self.h, dptr(xx), dptr(x0v), dptr(mv), mv.shape[1], lact))
+
+    def sweep_device(self, schedule="redblack"):
+        self._chk(self.lib.icm_sweep_device(self.h, SCHEDULES[schedule]))
+
+    def sweep_local(self):
+        self._chk(self.lib.icm_sweep_local(self.h))
+
+    def sweep_targets(self):
+        self._chk(self.lib.icm_sweep_targets(self.h))
+
+    def sweep_solve(self, schedule="redblack", colour=-1):
+        self._chk(self.lib.icm_sweep_solve(self.h, SCHEDULES[schedule], int(colour)))
+
+    def sweep_finish(self):
+        self._chk(self.lib.icm_sweep_finish(self.h))
+
+    def get_state(self):
+        x = np.zeros((3, self.T))
+        mo = np.zeros((2, self.L))
+        co = np.zeros(self.L)
+        ko = C.c_int64(0)
+        self._chk(self.lib.icm_get_state(self.h, dptr(x), dptr(mo), dptr(co), C.byref(ko)))
+        return x, mo, co, int(ko.value)
+
+    # ---- sharding ------------------------------------------------------------------------
+    def stats_stride(self):
+        return int(self.lib.icm_stats_stride(self.h))
+
+    def bind_exchange(self, stats_ptr, rank, world):
+        self._chk(self.lib.icm_bind_exchange(self.h, C.c_void_p(stats_ptr), int(rank), int(world)))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.icm_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def pose_buffer(self):
+        return self.lib.icm_pose_buffer(self.h)
+
+    # ---- inspection ----------------------------------------------------------------------
+    def association(self):
+        n = max(self.nnz, 1)
+        lab = np.zeros(n, dtype=np.int32)
+        tx, ty = np.zeros(n), np.zeros(n)
+        self._chk(self.lib.icm_get_association(self.h, iptr(lab), dptr(tx), dptr(ty)))
+        return lab[:self.nnz], tx[:self.nnz], ty[:self.nnz]
+
+    def raw_map(self):
+        y = np.zeros((2, self.L))
+        c = np.zeros(self.L)
+        la = C.c_int64(0)
+        self._chk(self.lib.icm_get_raw_map(self.h, dptr(y), dptr(c), C.byref(la)))
+        return y, c, int(la.value)
+
+    def _one(self, energy, two_sided, x, x_ant, x_pos, u, odo, bx, by, tx, ty):
+        odo = _f64(odo)
+        u = _f64(np.asarray(u, dtype=np.float64).reshape(2, -1))
+        bx, by, tx, ty = _f64(bx), _f64(by), _f64(tx), _f64(ty)
+        xa = _f64(np.asarray(x_ant, dtype=np.float64).reshape(3))
+        xp = _f64(np.asarray(x_pos, dtype=np.float64).reshape(3)) if x_pos is not None else None
+        out = np.zeros(6)
+        if energy:
+            xv = _f64(np.asarray(x, dtype=np.float64).reshape(3))
+            self._chk(self.lib.icm_energy_one(self.h, int(two_sided), dptr(xv), dptr(xa), dptr(xp), dptr(u), dptr(odo),
+                                              odo.shape[1], dptr(bx), dptr(by), dptr(tx), dptr(ty), len(bx), dptr(out)))
+            return float(out[0])
+        self._chk(self.lib.icm_solve_one(self.h, int(two_sided), dptr(xa), dptr(xp), dptr(u), dptr(odo), odo.shape[1],
+                                         dptr(bx), dptr(by), dptr(tx), dptr(ty), len(bx), dptr(out)))
+        return out
+
+    def solve_one(self, two_sided, x_ant, x_pos, u, odo, bx, by, tx, ty):
+        """minimizar_xn (two_sided) / minimizar_x on the GPU -> [x, y, theta, f, nit, nfev]."""
+        return self._one(False, two_sided, None, x_ant, x_pos, u, odo, bx, by, tx, ty)
+
+    def energy_one(self, two_sided, x, x_ant, x_pos, u, odo, bx, by, tx, ty):
+        """fun_xn (two_sided) / fun_x at pose x, evaluated on the GPU."""
+        return self._one(True, two_sided, x, x_ant, x_pos, u, odo, bx, by, tx, ty)
+
+    def set_brute_force(self, on):
+        self._chk(self.lib.icm_set_brute_force(self.h, int(bool(on))))
+
+    def enable_timing(self, on=True):
+        self._chk(self.lib.icm_enable_timing(self.h, int(bool(on))))
+        self._chk(self.lib.icm_reset_timing(self.h))
+
+    def kernel_times(self):
+        out = {}
+        for i in range(self.lib.icm_kernel_count(self.h)):
+            name = C.c_char_p()
+            ms = C.c_double(0)
+            n = C.c_int64(0)
+            self._chk(self.lib.icm_kernel_time(self.h, i, C.byref(name), C.byref(ms), C.byref(n)))
+            out[name.value.decode()] = (ms.value, n.value)
+        return out
+
+    def last_stats(self):
+        a = np.zeros(4, dtype=np.int64)
+        self._chk(self.lib.icm_last_stats(self.h, lptr(a)))
+        return dict(kept_beams=int(a[0]), entries=int(a[1]), new_landmarks=int(a[2]), labels=int(a[3]))

@@ -1,0 +1,168 @@
+/*
+ * icmslam.h -- C-ABI of the MI355X-native offline ICM sweep.
+ *
+ * The reference (Seba-san/icm-slam) is pure Python and has no FFI; the boundary it
+ * exposes for this path is the Python method
+ *     mapa_refinado, x = ICM_ROS.iterations_process_offline(mapa_viejo, x)
+ * (reference scripts/ICM_ROS.py:121-164, called from scripts/example.py:52 and
+ * scripts/ICM_ROS.py:301).  The entry points below are what a ctypes binding inside that
+ * method binds to; each cites the reference code it replaces.
+ *
+ * Conventions: plain pointers and sizes only; arrays are C-contiguous float64 in the
+ * reference's own layouts ((3,T) poses = all x, then all y, then all theta); every
+ * function returns 0 on success or a negative ICM_ERR_* code (never throws);
+ * icm_last_error() gives the text.  One handle per GPU / rank; calls on one handle must
+ * be serialised by the caller (the reference is non-reentrant as well).
+ * Host pointers are borrowed for the duration of the call only.
+ */
+#ifndef ICMSLAM_H
+#define ICMSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICM_OK 0
+#define ICM_ERR_ARG (-1)         /* bad argument / call order                              */
+#define ICM_ERR_HIP (-2)         /* HIP runtime error                                      */
+#define ICM_ERR_INDEX (-3)       /* reference would raise IndexError (label >= L, or a     */
+                                 /* no-beam last pose, scripts/ICM_ROS.py:144)             */
+#define ICM_ERR_EMPTY_MAP (-4)   /* Mapa.filtrar left no landmark (reference: ValueError)  */
+#define ICM_ERR_CAPACITY (-5)    /* a scan touched more distinct landmarks than supported  */
+#define ICM_ERR_UNSUPPORTED (-6) /* input outside what this build implements               */
+
+#define ICM_SCHEDULE_SEQUENTIAL 0 /* reference Gauss-Seidel order (scripts/ICM_ROS.py:141) */
+#define ICM_SCHEDULE_REDBLACK 1   /* odd poses, then even poses (parallel)     */
+
+/* Numeric options of ConfigICM (reference scripts/ICM_SLAM_tools.py:60-102). */
+typedef struct icm_config {
+    double deltat;          /* sampling period                                            */
+    double Q[2];            /* diag of the observation weight                             */
+    double R[3];            /* diag of the motion-model weight                            */
+    double cte_odom;        /* odometry weight                                            */
+    double cota;            /* min. observation count for a landmark to survive filtrar   */
+    double dist_thr;        /* association gate / merge distance                          */
+    double rango_laser_max; /* max laser range                                            */
+    int64_t L;              /* landmark capacity (columns of the running map)             */
+} icm_config;
+
+typedef struct icm_handle icm_handle;
+
+/* ---- life cycle ---------------------------------------------------------------------- */
+/* Create a solver bound to HIP device `device`.  Fails (ICM_ERR_HIP) if no GPU: there is
+ * no CPU fallback. */
+int icm_create(const icm_config *cfg, int device, icm_handle **out);
+int icm_destroy(icm_handle *h);
+const char *icm_last_error(const icm_handle *h); /* h may be NULL: last create error */
+/* Launch all work on an existing HIP stream (e.g. torch's current stream) instead of the
+ * handle's own. */
+int icm_set_stream(icm_handle *h, void *hip_stream);
+
+/* ---- sequence upload + scan pre-filter ------------------------------------------------ */
+/* Replaces the attributes the sweep reads from the ICM_ROS object: `mediciones` (B,T),
+ * `odometria` (3,T), `u` (2,T) (reference scripts/ICM_ROS.py:20-24,131,141-142).
+ *   ranges  [(t_end-t_begin)*B] pose-major: the scans of poses t_begin..t_end-1 of this
+ *           rank's shard (the transpose of the reference's beam-major `mediciones`)
+ *   odo     [3*T], u [2*T]   full sequence, reference layout
+ *   cosb,sinb [B]  cos/sin of the beam bearings (reference: k*pi/180,
+ *           scripts/ICM_SLAM_tools.py:44,51), computed by the host
+ * Single GPU: t_begin = 0, t_end = T. */
+int icm_upload(icm_handle *h, const double *ranges, const double *odo, const double *u,
+               const double *cosb, const double *sinb, int64_t T, int64_t B, int64_t t_begin,
+               int64_t t_end);
+/* filtrar_z for every scan of the shard, once per sequence (reference
+ * scripts/ICM_SLAM_tools.py:22-58, called per pose per sweep at scripts/ICM_ROS.py:130,142).
+ * nnz_out = number of kept beams. */
+int icm_prefilter(icm_handle *h, int64_t *nnz_out);
+/* Copy the kept beams out (parity tests): offsets[nloc+1], then per kept beam its scan row
+ * index, range d, body x, body y (columns 0,2,3 of filtrar_z's rows; column 1 is
+ * bearing(index)).  Any output pointer may be NULL. */
+int icm_get_kept(icm_handle *h, int64_t *offsets, int32_t *beam_index, double *d, double *bx,
+                 double *by);
+
+/* ---- one sweep through host arrays (the drop-in call) --------------------------------- */
+/* iterations_process_offline (reference scripts/ICM_ROS.py:121-164).
+ *   x        [3*T] in/out, updated in place like the reference
+ *   x0       [3]   self.x0, used to project scan 0 (scripts/ICM_ROS.py:125,137)
+ *   map_in   [2*K] mapa_viejo (2,K), not modified
+ *   lact_in  Mapa.landmarks_actuales on entry (normally == K)
+ *   map_out  [2*L] filtered map, zero padded like Mapa.filtrar's return
+ *   counts_out [L] Mapa.cant_obs_i after the sweep
+ *   K_out    Mapa.landmarks_actuales after the sweep (columns of mapa_refinado)
+ * If scan 0 has no kept beams the reference returns its inputs untouched; so does this
+ * (K_out = -1 signals that case). */
+int icm_sweep(icm_handle *h, double *x, const double *x0, const double *map_in, int64_t K,
+              int64_t lact_in, int schedule, double *map_out, double *counts_out, int64_t *K_out);
+
+/* ---- device-resident sweeps (state stays in HBM between sweeps) ------------------------ */
+int icm_set_state(icm_handle *h, const double *x, const double *x0, const double *map_in,
+                  int64_t K, int64_t lact_in);
+/* One sweep on the resident state; the refined map becomes the next sweep's mapa_viejo
+ * (reference driver loop scripts/ICM_ROS.py:298-311). */
+int icm_sweep_device(icm_handle *h, int schedule);
+int icm_get_state(icm_handle *h, double *x, double *map_out, double *counts_out, int64_t *K_out);
+
+/* ---- sharded sweep: the same sweep cut at the one point where ranks exchange data ------ */
+/* Bind the exchange buffers (device memory owned by the caller, e.g. torch tensors):
+ *   stats_all [world * icm_stats_stride()] doubles: rank r's landmark sufficient
+ *             statistics live at stats_all + r*stride; the caller all-gathers it (RCCL)
+ *             between icm_sweep_local() and icm_sweep_solve().
+ *   x_all     [3*T] the replicated pose array itself (the caller all-gathers the shard
+ *             blocks after each colour); NULL = use the handle's own pose buffer. */
+int64_t icm_stats_stride(const icm_handle *h);
+int icm_bind_exchange(icm_handle *h, void *stats_all_dev, int rank, int world);
+void *icm_pose_buffer(icm_handle *h);                 /* device pointer of x (3,T)          */
+int icm_sweep_local(icm_handle *h);                   /* phase A + local statistics          */
+int icm_sweep_targets(icm_handle *h);                 /* prefix over ranks -> targets, map   */
+int icm_sweep_solve(icm_handle *h, int schedule, int colour); /* colour 1 = odd, 0 = even,  */
+                                                      /* -1 = both / sequential             */
+int icm_sweep_finish(icm_handle *h);                  /* Mapa.filtrar, next mapa_viejo       */
+
+/* ---- kernel-level entry points for parity tests ---------------------------------------- */
+/* Labels of every kept beam after phase A of the last sweep (reference `c` of
+ * Mapa.actualizar, scripts/ICM_SLAM_tools.py:170-181; new landmarks carry their fresh id)
+ * and the running-mean targets y[:,c] each pose was solved against (scripts/ICM_ROS.py:152). */
+int icm_get_association(icm_handle *h, int32_t *labels, double *target_x, double *target_y);
+/* Raw running map before Mapa.filtrar: y (2,L) and cant_obs_i (L), landmarks_actuales. */
+int icm_get_raw_map(icm_handle *h, double *y, double *counts, int64_t *lact);
+/* One Nelder-Mead solve on the GPU (reference minimizar_xn / minimizar_x,
+ * scripts/ICM_ROS.py:209-218,254-260).  two_sided=1: fun_xn with x_pos, u[2x2 col-major as
+ * (2,2) numpy u[:,t-1:t+1]], odo (3,3) = odometria[:,t-1:t+2]; two_sided=0: fun_x with
+ * odo (3,2).  beams (n): body x,y; targets (n): y[:,c].  out[6] = x,y,theta,f,nit,nfev. */
+int icm_solve_one(icm_handle *h, int two_sided, const double *x_ant, const double *x_pos,
+                  const double *u, const double *odo, int odo_cols, const double *bx,
+                  const double *by, const double *tx, const double *ty, int64_t n, double *out);
+/* Energy only, same arguments, at pose `x`: out[0] = fun_xn / fun_x (scripts/ICM_ROS.py:220-278). */
+int icm_energy_one(icm_handle *h, int two_sided, const double *x, const double *x_ant,
+                   const double *x_pos, const double *u, const double *odo, int odo_cols,
+                   const double *bx, const double *by, const double *tx, const double *ty,
+                   int64_t n, double *out);
+
+/* ---- host-side map prune/merge (no GPU needed) ----------------------------------------- */
+/* Mapa.filtrar (reference scripts/ICM_SLAM_tools.py:204-265): y (2,L) row-major, counts (L),
+ * lact in/out.  y_out (2,L) zero padded, counts_out (L). */
+int icm_filtrar(const icm_config *cfg, const double *y, const double *counts, int64_t lact,
+                double *y_out, double *counts_out, int64_t *lact_out);
+
+/* Test hook: run phase A with the brute-force kernel (every beam against every landmark of
+ * mapa_viejo, table tiled through LDS) instead of the grid search.  Same results. */
+int icm_set_brute_force(icm_handle *h, int on);
+
+/* ---- instrumentation -------------------------------------------------------------------- */
+/* When enabled, every kernel launch of a sweep is bracketed by HIP events on the handle's
+ * stream; icm_kernel_time() returns accumulated ms and launch count per kernel name. */
+int icm_enable_timing(icm_handle *h, int on);
+int icm_reset_timing(icm_handle *h);
+int icm_kernel_count(const icm_handle *h);
+int icm_kernel_time(icm_handle *h, int idx, const char **name, double *ms, int64_t *launches);
+/* Counters of the last sweep: [0] kept beams, [1] (pose,landmark) entries, [2] poses with
+ * new landmarks, [3] labels in use (landmarks_actuales before filtrar). */
+int icm_last_stats(const icm_handle *h, int64_t *out4);
+const char *icm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICMSLAM_H */
