@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native ICM sweep: ICM pose-updates/s over full sweeps.
+
+    python bench.py                      # 1 GPU, workload S2 (100k poses / 10k landmarks / 720 beams)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full ICM sweep (reference `iterations_process_offline`, scripts/ICM_ROS.py:121-164:
+association of every kept beam, running-mean map, one Nelder-Mead solve per pose, map
+prune/merge) over the whole synthetic sequence, which is resident in HBM when timing starts.
+Poses are solved in the red-black order (the reference's sequential order is one dependent
+chain of T-1 solves and is used for parity, not throughput).  With N > 1 the SAME sequence is
+sharded by pose blocks over the ranks (strong scaling), with one all-gather of the landmark
+sufficient statistics and the pose-block exchanges per sweep.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with the two extra objects
+`roofline` (dominant kernel, measured with HIP events on the launch stream) and
+`cpu_baseline` (the NumPy oracle timed on one host core on a bounded prefix of the same
+workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "icm-slam_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch):
+    """Compulsory HBM bytes ONE launch of `kernel` moves: every array
+    the kernel must read or write once, no re-reads.  nnz = kept beams, E = (pose, landmark)
+    entries, nloc = poses of the shard, L = landmark capacity."""
+    per_sweep = {
+        # read body x,y of every kept beam + pose; write one label per beam
+        "k_associate": nnz * (16 + 4) + nloc * (24 + 8),
+        # read body x,y + label, write entry index; write entries (label,k,sum x,sum y)
+        "k_group": nnz * (16 + 4 + 4) + E * 24 + nloc * (24 + 16),
+        "k_compact": E * (24 + 32) + nloc * 16,
+        "radix_sort_pairs": E * 8 * 2 * 2,
+        "k_lm_bounds": (L + 1) * 4,
+        "k_lm_local": E * (4 + 20) + L * 24,
+        "k_stats_prefix": L * (24 + 24 + 24),
+        "k_lm_chain": E * (4 + 20 + 16) + L * 24,
+        "k_beam_targets": nnz * (4 + 16) + E * 16,
+        # both colours together: body x,y + target x,y of every beam, pose in/out + odometry + u
+        "k_solve": nnz * 32 + nloc * 88,
+        "k_exscan_i32": nloc * 8,
+    }
+    return per_sweep.get(kernel, 0) / max(nlaunch, 1)
+
+
+def survey_bytes_per_pose(B, Kt, K, T):
+    """whole-sweep compulsory bytes per pose update."""
+    return 8 * B + 88 + 64 * Kt + 40.0 * K / T
+
+
+def cpu_baseline(wl, cfg, n_pose, schedule):
+    """The NumPy oracle (reference restatement, one core) on the first n_pose poses of the
+    same workload at full landmark count."""
+    from oracle import icm_oracle as o
+    ocfg = o.OracleConfig.from_config(cfg)
+    scans = np.ascontiguousarray(wl.scans[:n_pose].T)
+    u, odo = wl.u[:, :n_pose], wl.odometry[:, :n_pose]
+    st = o.MapState(ocfg, wl.K)
+    x = np.ascontiguousarray(wl.x_init[:, :n_pose])
+    t0 = time.perf_counter()
+    kept = o.prefilter_all(scans, ocfg)
+    t1 = time.perf_counter()
+    try:
+        o.sweep(ocfg, st, scans, u, odo, wl.x0, wl.map_init.copy(), x, schedule=schedule, kept=kept)
+    except ValueError:
+        pass  # a short prefix may leave no landmark above `cota`; the sweep work is done by then
+    t2 = time.perf_counter()
+    return (n_pose - 1) / (t2 - t1), t1 - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="S2", help="S2 (BASELINE metric config), S1, tiny")
+    ap.add_argument("--cpu-poses", type=int, default=-1, help="prefix length of the CPU baseline (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import WORKLOADS, make_workload
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    T, K, B = WORKLOADS[args.workload]
+    blk = (T + world - 1) // world
+    t_begin, t_end = min(rank * blk, T), min((rank + 1) * blk, T)
+    t0 = time.perf_counter()
+    wl = make_workload(T, K, B, t_begin=t_begin, t_end=t_end)
+    t_gen = time.perf_counter() - t0
+    cfg = ConfigICM(D=wl.config)
+    schedule = "redblack"
+
+    eng = SweepEngine(cfg, local_rank)
+    t0 = time.perf_counter()
+    eng.upload(wl.scans, wl.odometry, wl.u, t_begin=t_begin, t_end=t_end, pose_major=True)
+    t_upload = time.perf_counter() - t0
+    if world > 1:
+        from icmslam_hip.sharded import ShardedSweep
+        runner = ShardedSweep(eng, rank, world, T)
+        runner.set_state(wl.map_init, wl.x_init, wl.x0)
+        step = lambda: runner.sweep(schedule)  # noqa: E731
+    else:
+        eng.set_state(wl.map_init, wl.x_init, wl.x0)
+        step = lambda: eng.sweep_device(schedule)  # noqa: E731
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    value = (T - 1) * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream
+    roof = None
+    st = eng.last_stats()
+    if not args.no_roofline:
+        eng.enable_timing(True)
+        nroof = 3
+        for _ in range(nroof):
+            step()
+        fence()
+        kt = {k: v for k, v in eng.kernel_times().items() if v[1] > 0 and k != "k_prefilter"}
+        eng.enable_timing(False)
+        dom = max(kt, key=lambda k: kt[k][0])
+        ms, n = kt[dom]
+        avg_ms = ms / n
+        nl = n / nroof
+        abytes = algorithmic_bytes(dom, st["kept_beams"], st["entries"], eng.nloc, eng.L, nl)
+        ach = abytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "avg_launch_ms": round(avg_ms, 4), "launches_per_sweep": nl,
+                "algorithmic_bytes_per_launch": int(abytes),
+                "kernels_ms_per_sweep": {k: round(v[0] / nroof, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}}
+        Kt = st["entries"] / max(eng.nloc, 1)
+        sweep_bytes = survey_bytes_per_pose(B, Kt, K, T) * (T - 1)
+        roof["sweep_algorithmic_GBps"] = round(sweep_bytes / (ms_per_step * 1e-3) / 1e9, 2)
+        roof["sweep_frac_of_hbm_peak"] = round(roof["sweep_algorithmic_GBps"] / HBM_PEAK_GBS, 5)
+
+    out = {
+        "metric": "ICM pose-updates/sec (full sweep)", "value": round(value, 1), "unit": "pose-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: synthetic %d poses / %d landmarks / %d beams, red-black ICM sweep" % (args.workload, T, K, B),
+                   "schedule": schedule, "poses": T, "landmarks": K, "beams": B, "kept_beams": st["kept_beams"] if world == 1 else None,
+                   "parallelism": "pose-shard x%d" % world},
+        "setup_s": {"generate": round(t_gen, 2), "upload_and_prefilter": round(t_upload, 2)},
+    }
+    if roof is not None:
+        out["roofline"] = roof
+    if rank == 0 and world == 1 and args.cpu_poses != 0:
+        n_cpu = args.cpu_poses if args.cpu_poses > 0 else {"S2": 400, "S1": 1500}.get(args.workload, T)
+        n_cpu = min(n_cpu, t_end)
+        v, tpre = cpu_baseline(wl, cfg, n_cpu, schedule)
+        out["cpu_baseline"] = {"value": round(v, 2), "unit": "pose-updates/s", "cores": 1, "kind": "port",
+                               "sample": "NumPy oracle (oracle/icm_oracle.py), one red-black sweep over the first %d poses of "
+                                         "the same sequence at the full %d-landmark map; host has %d cores" % (n_cpu, K, os.cpu_count())}
+        out["gpu_over_cpu"] = round(value / v, 1)
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

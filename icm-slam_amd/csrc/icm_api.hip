@@ -373,6 +373,13 @@ int icm_bind_exchange(icm_handle* h, void* stats_all_dev, int rank, int world) {
     return ICM_OK;
 }
 
+int icm_bind_pose_buffer(icm_handle* h, void* x_dev) {
+    if (!h) return ICM_ERR_ARG;
+    if (!x_dev) FAIL(h, ICM_ERR_ARG, "icm_bind_pose_buffer: null buffer");
+    h->x = reinterpret_cast<double*>(x_dev);
+    return ICM_OK;
+}
+
 void* icm_pose_buffer(icm_handle* h) {
     if (!h) return nullptr;
     if (!h->x) {
@@ -659,6 +666,8 @@ int icm_energy_one(icm_handle* h, int two_sided, const double* x, const double* 
                    const double* u, const double* odo, int odo_cols, const double* bx, const double* by,
                    const double* tx, const double* ty, int64_t n, double* out) {
     if (h && !x) FAIL(h, ICM_ERR_ARG, "icm_energy_one: null x");
+    if (two_sided == 2)  // observation energy h(x) only
+        return run_one(h, 2, 0, x, x_ant, nullptr, u, odo, odo_cols, bx, by, tx, ty, n, out);
     return run_one(h, 1, two_sided, x, x_ant, x_pos, u, odo, odo_cols, bx, by, tx, ty, n, out);
 }
 

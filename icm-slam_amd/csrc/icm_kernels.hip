@@ -650,7 +650,9 @@ __global__ __launch_bounds__(kWave) void k_solve_one(OneArgs a) {
     make_ctx(c, a.two_sided, p + 3, p + 6, p + 9, p + 11, p + 13, p + 16, p + 19);
     Items it{a.bx, a.by, a.tx, a.ty, nullptr, 0.0, a.n};
     double out[6] = {0, 0, 0, 0, 0, 0};
-    if (a.energy_only) {
+    if (a.energy_only == 2) {
+        out[3] = obs_energy(c, it, p[0], p[1], p[2], lane);
+    } else if (a.energy_only) {
         out[3] = pose_energy(c, it, p[0], p[1], p[2], lane);
     } else {
         double sx, sy, st;

@@ -201,6 +201,9 @@ class SweepEngine:
     def set_stream(self, stream_ptr):
         self._chk(self.lib.icm_set_stream(self.h, C.c_void_p(stream_ptr)))
 
+    def bind_pose_buffer(self, ptr):
+        self._chk(self.lib.icm_bind_pose_buffer(self.h, C.c_void_p(ptr)))
+
     def pose_buffer(self):
         return self.lib.icm_pose_buffer(self.h)
 

@@ -109,11 +109,15 @@ int icm_get_state(icm_handle *h, double *x, double *map_out, double *counts_out,
  *   stats_all [world * icm_stats_stride()] doubles: rank r's landmark sufficient
  *             statistics live at stats_all + r*stride; the caller all-gathers it (RCCL)
  *             between icm_sweep_local() and icm_sweep_solve().
- *   x_all     [3*T] the replicated pose array itself (the caller all-gathers the shard
- *             blocks after each colour); NULL = use the handle's own pose buffer. */
+ * The pose array is replicated; the caller all-gathers the shard blocks after each colour
+ * (see icm_bind_pose_buffer). */
 int64_t icm_stats_stride(const icm_handle *h);
 int icm_bind_exchange(icm_handle *h, void *stats_all_dev, int rank, int world);
-void *icm_pose_buffer(icm_handle *h);                 /* device pointer of x (3,T)          */
+/* Use caller-owned device memory for the poses: (T,3) doubles, pose-major (a contiguous
+ * block of poses is a contiguous block of memory, so shards all-gather in place).  Call
+ * before icm_set_state. */
+int icm_bind_pose_buffer(icm_handle *h, void *x_dev);
+void *icm_pose_buffer(icm_handle *h);                 /* device pointer of x (T,3)          */
 int icm_sweep_local(icm_handle *h);                   /* phase A + local statistics          */
 int icm_sweep_targets(icm_handle *h);                 /* prefix over ranks -> targets, map   */
 int icm_sweep_solve(icm_handle *h, int schedule, int colour); /* colour 1 = odd, 0 = even,  */
@@ -134,7 +138,8 @@ int icm_get_raw_map(icm_handle *h, double *y, double *counts, int64_t *lact);
 int icm_solve_one(icm_handle *h, int two_sided, const double *x_ant, const double *x_pos,
                   const double *u, const double *odo, int odo_cols, const double *bx,
                   const double *by, const double *tx, const double *ty, int64_t n, double *out);
-/* Energy only, same arguments, at pose `x`: out[0] = fun_xn / fun_x (scripts/ICM_ROS.py:220-278). */
+/* Energy only, same arguments, at pose `x`: out[0] = fun_xn / fun_x (scripts/ICM_ROS.py:220-278);
+ * two_sided = 2 evaluates the observation energy h(x) alone (scripts/ICM_ROS.py:171-200). */
 int icm_energy_one(icm_handle *h, int two_sided, const double *x, const double *x_ant,
                    const double *x_pos, const double *u, const double *odo, int odo_cols,
                    const double *bx, const double *by, const double *tx, const double *ty,
