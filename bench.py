@@ -39,20 +39,22 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch):
     the kernel must read or write once, no re-reads.  nnz = kept beams, E = (pose, landmark)
     entries, nloc = poses of the shard, L = landmark capacity."""
     per_sweep = {
-        # read body x,y of every kept beam + pose; write one label per beam
-        "k_associate": nnz * (16 + 4) + nloc * (24 + 8),
-        # read body x,y + label, write entry index; write entries (label,k,sum x,sum y)
-        "k_group": nnz * (16 + 4 + 4) + E * 24 + nloc * (24 + 16),
-        "k_compact": E * (24 + 32) + nloc * 16,
+        # read body x,y of every kept beam + pose; write one staged entry (label,k,sum bx,sum by)
+        # per distinct landmark of the scan
+        "k_assoc_group": nnz * 16 + E * 24 + nloc * (24 + 8 + 8),
+        "k_associate_brute": nnz * (16 + 4) + nloc * 32,
+        # staged entries in; compact entries out (key,val,k,mean b,sum w); pose + scatter
+        "k_compact": E * 24 + E * 44 + nloc * (24 + 24 + 24 + 8),
         "radix_sort_pairs": E * 8 * 2 * 2,
         "k_lm_bounds": (L + 1) * 4,
-        "k_lm_local": E * (4 + 20) + L * 24,
+        "k_lm_scan_totals": E * (4 + 20) + L * (8 + 24),
         "k_stats_prefix": L * (24 + 24 + 24),
-        "k_lm_chain": E * (4 + 20 + 16) + L * 24,
+        # sorted entry ids + gathered (k, sum wx, sum wy) in; target per entry out; raw map out
+        "k_lm_scan": E * (4 + 20 + 16) + L * (8 + 24),
         "k_beam_targets": nnz * (4 + 16) + E * 16,
-        # both colours together: body x,y + target x,y of every beam, pose in/out + odometry + u
-        "k_solve": nnz * 32 + nloc * 88,
-        "k_exscan_i32": nloc * 8,
+        # both colours together: (k, mean b, target) of every entry; pose in/out, odometry, u, scatter
+        "k_solve": E * 36 + nloc * (88 + 24 + 8),
+        "k_scan": nloc * 16,
     }
     return per_sweep.get(kernel, 0) / max(nlaunch, 1)
 

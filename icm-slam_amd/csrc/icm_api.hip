@@ -23,12 +23,12 @@ namespace {
 std::string g_create_err;
 
 enum KernelId {
-    KID_PREFILTER = 0, KID_SCAN, KID_ASSOCIATE, KID_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_LOCAL,
-    KID_STATS_PREFIX, KID_LM_CHAIN, KID_BEAM_TARGETS, KID_SOLVE, KID_COUNT
+    KID_PREFILTER = 0, KID_SCAN, KID_ASSOC_BRUTE, KID_ASSOC_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_TOTALS,
+    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_COUNT
 };
-const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_exscan_i32", "k_associate", "k_group", "k_compact",
-                                       "radix_sort_pairs", "k_lm_bounds", "k_lm_local", "k_stats_prefix",
-                                       "k_lm_chain", "k_beam_targets", "k_solve"};
+const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_scan", "k_associate_brute", "k_assoc_group", "k_compact",
+                                       "radix_sort_pairs", "k_lm_bounds", "k_lm_scan_totals", "k_stats_prefix",
+                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve"};
 
 template <class T>
 struct DevBuf {
@@ -64,7 +64,7 @@ struct icm_handle {
     bool uploaded = false, prefiltered = false, have_state = false;
     DevBuf<double> ranges, cosb, sinb, odo, u;
     DevBuf<int> nkept, boff, bk;
-    DevBuf<double> bd, bx, by;
+    DevBuf<double> bd, bx, by, pose_s2;
     std::vector<int> h_boff;
     int64_t nnz = 0;
 
@@ -82,16 +82,17 @@ struct icm_handle {
     DevBuf<double> g_lx, g_ly, mapx, mapy;
 
     // per-sweep
-    DevBuf<int> label, bloc, st_label, st_k, nent, isnew, ent_off, new_rank, e_val, e_k, sval, lm_off, flags;
+    DevBuf<int> label, bloc, st_label, st_k, nent, isnew, ent_off, new_rank, e_val, e_k, sval, lm_off, flags, scan_tot;
     DevBuf<unsigned> e_key, skey;
-    DevBuf<double> st_sx, st_sy, e_sx, e_sy, tgt_x, tgt_y, btx, bty;
+    DevBuf<double> st_sx, st_sy, e_bx, e_by, e_wx, e_wy, e_wrx, e_wry, pose_c, pose_m, tgt_x, tgt_y, btx, bty;
     DevBuf<double> stats_own, off_sx, off_sy, off_n, y_raw, cnt_raw, diag;
     DevBuf<unsigned char> sort_tmp;
     double* stats_all = nullptr;
     int rank = 0, world = 1;
     int64_t E = 0, n_new_loc = 0, lact_raw = 0;
     int lact0 = 0;
-    bool brute = false;
+    bool brute = false, debug = false, per_beam = false, assoc_kept = false;
+    int form = 0;  // 0 moments (lane per pose), 1 per beam, 2 per entry (wave per pose)
     int *pin_i = nullptr;
     double* pin_d = nullptr;  // pinned staging: raw map download (3L)
     std::vector<double> h_yraw, h_cntraw;
@@ -186,12 +187,12 @@ int icm_destroy(icm_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf<double>* dd[] = {&h->ranges, &h->cosb, &h->sinb, &h->odo, &h->u, &h->bd, &h->bx, &h->by, &h->x_own, &h->x0,
-                            &h->g_lx, &h->g_ly, &h->mapx, &h->mapy, &h->st_sx, &h->st_sy, &h->e_sx, &h->e_sy, &h->tgt_x,
+                            &h->g_lx, &h->g_ly, &h->mapx, &h->mapy, &h->st_sx, &h->st_sy, &h->e_bx, &h->e_by, &h->e_wx, &h->e_wy, &h->e_wrx, &h->e_wry, &h->pose_m, &h->pose_c, &h->pose_s2, &h->tgt_x,
                             &h->tgt_y, &h->btx, &h->bty, &h->stats_own, &h->off_sx, &h->off_sy, &h->off_n, &h->y_raw,
                             &h->cnt_raw, &h->diag};
     for (auto* b : dd) b->release();
     DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->g_id, &h->label, &h->bloc, &h->st_label, &h->st_k,
-                         &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags};
+                         &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags, &h->scan_tot};
     for (auto* b : di) b->release();
     h->e_key.release();
     h->skey.release();
@@ -253,8 +254,8 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prefilter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prefilter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nb = nblocks_waves(nloc);
-    TIMED(h, KID_PREFILTER, (k_prefilter<false><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, h->nkept.p, nullptr, nullptr, nullptr, nullptr, nullptr)));
-    TIMED(h, KID_SCAN, (k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->nkept.p, h->boff.p, nloc)));
+    TIMED(h, KID_PREFILTER, (k_prefilter<false><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, h->nkept.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)));
+    k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->nkept.p, h->boff.p, nloc);
     h->h_boff.assign((size_t)nloc + 1, 0);
     HIPCHK(h, hipMemcpyAsync(h->h_boff.data(), h->boff.p, ((size_t)nloc + 1) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -264,14 +265,20 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->bd.reserve(nz));
     HIPCHK(h, h->bx.reserve(nz));
     HIPCHK(h, h->by.reserve(nz));
-    TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p)));
+    HIPCHK(h, h->pose_s2.reserve(3 * (size_t)nloc));
+    HIPCHK(h, h->pose_c.reserve(3 * (size_t)nloc));
+    HIPCHK(h, h->pose_m.reserve(17 * (size_t)nloc));
+    TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p)));
     // per-sweep buffers sized by the kept beams
     HIPCHK(h, h->label.reserve(nz)); HIPCHK(h, h->bloc.reserve(nz)); HIPCHK(h, h->st_label.reserve(nz));
     HIPCHK(h, h->st_k.reserve(nz)); HIPCHK(h, h->st_sx.reserve(nz)); HIPCHK(h, h->st_sy.reserve(nz));
     HIPCHK(h, h->btx.reserve(nz)); HIPCHK(h, h->bty.reserve(nz));
     HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz));
-    HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_sx.reserve(nz));
-    HIPCHK(h, h->e_sy.reserve(nz)); HIPCHK(h, h->tgt_x.reserve(nz)); HIPCHK(h, h->tgt_y.reserve(nz));
+    HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_bx.reserve(nz));
+    HIPCHK(h, h->e_by.reserve(nz)); HIPCHK(h, h->e_wx.reserve(nz)); HIPCHK(h, h->e_wy.reserve(nz));
+    HIPCHK(h, h->e_wrx.reserve(nz)); HIPCHK(h, h->e_wry.reserve(nz));
+    HIPCHK(h, h->tgt_x.reserve(nz)); HIPCHK(h, h->tgt_y.reserve(nz));
+    HIPCHK(h, h->scan_tot.reserve(2 * ((size_t)nloc / kScanTile + 2)));
     HIPCHK(h, h->nent.reserve((size_t)nloc + 1)); HIPCHK(h, h->isnew.reserve((size_t)nloc + 1));
     HIPCHK(h, h->ent_off.reserve((size_t)nloc + 1)); HIPCHK(h, h->new_rank.reserve((size_t)nloc + 1));
     const size_t L = (size_t)h->cfg.L;
@@ -413,36 +420,46 @@ int icm_sweep_local(icm_handle* h) {
     const int km = (int)std::min(h->K, h->lact);
     const int nbw = nblocks_waves(nloc);
     HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
+    GridView gv{h->grid.gx0, h->grid.gy0, h->grid.inv, h->grid.nx, h->grid.ny, h->g_cell.p, h->g_lx.p, h->g_ly.p, h->g_id.p};
+    const bool dbg = h->debug || h->per_beam;
+    h->assoc_kept = dbg;
+#define ASSOC_GROUP(PRE, DBG)                                                                                      \
+    TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG><<<nbw, kBlock, 0, h->stream>>>(                             \
+        h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->label.p,       \
+        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p)))
     if (h->brute) {
-        TIMED(h, KID_ASSOCIATE, (k_associate_brute<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->mapx.p, h->mapy.p, km, h->cfg.dist_thr, h->label.p)));
+        TIMED(h, KID_ASSOC_BRUTE, (k_associate_brute<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->mapx.p, h->mapy.p, km, h->cfg.dist_thr, h->label.p)));
+        if (dbg) ASSOC_GROUP(true, true); else ASSOC_GROUP(true, false);
     } else {
-        GridView gv{h->grid.gx0, h->grid.gy0, h->grid.inv, h->grid.nx, h->grid.ny, h->g_cell.p, h->g_lx.p, h->g_ly.p, h->g_id.p};
-        TIMED(h, KID_ASSOCIATE, (k_associate<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->label.p)));
+        if (dbg) ASSOC_GROUP(false, true); else ASSOC_GROUP(false, false);
     }
-    TIMED(h, KID_GROUP, (k_group<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->label.p, h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p)));
-    TIMED(h, KID_SCAN, (k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->nent.p, h->ent_off.p, nloc)));
-    TIMED(h, KID_SCAN, (k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->isnew.p, h->new_rank.p, nloc)));
+#undef ASSOC_GROUP
+    const int ntiles = (nloc + kScanTile - 1) / kScanTile;
+    TIMED(h, KID_SCAN, (k_scan_tiles<<<ntiles, kBlock, 0, h->stream>>>(h->nent.p, h->isnew.p, h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc)));
+    TIMED(h, KID_SCAN, (k_scan_fix<<<ntiles, kBlock, 0, h->stream>>>(h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc, ntiles)));
     HIPCHK(h, hipMemcpyAsync(h->pin_i, h->ent_off.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->pin_i + 1, h->new_rank.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->E = h->pin_i[0];
     h->n_new_loc = h->pin_i[1];
-    if (h->pin_i[2]) FAIL(h, ICM_ERR_CAPACITY, "sweep: a scan touched more than 256 distinct landmarks");
+    if (h->pin_i[2]) FAIL(h, ICM_ERR_CAPACITY, "sweep: a scan touched more than 192 distinct landmarks");
     if ((int64_t)h->lact0 + h->n_new_loc > L)
         FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
     const int nlab = h->lact0 + (int)h->n_new_loc;
     const int E = (int)h->E;
-    TIMED(h, KID_COMPACT, (k_compact<<<nbw, kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->e_key.p, h->e_val.p, h->e_k.p, h->e_sx.p, h->e_sy.p)));
+    TIMED(h, KID_COMPACT, (k_compact<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, h->e_key.p, h->e_val.p, h->e_k.p, h->e_bx.p, h->e_by.p, h->e_wx.p, h->e_wy.p, h->e_wrx.p, h->e_wry.p, h->pose_c.p)));
     int bits = 1;
     while ((1ll << bits) < (int64_t)nlab + 1) ++bits;
     size_t tmp_bytes = h->sort_tmp.cap;
     if (E > 0)
         TIMED(h, KID_SORT, HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp.p, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, (size_t)E, 0, bits, h->stream)));
     TIMED(h, KID_LM_BOUNDS, (k_lm_bounds<<<nblocks_threads(nlab + 1), kBlock, 0, h->stream>>>(h->skey.p, E, nlab, h->lm_off.p)));
-    double* stats_mine = h->world > 1 ? h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h) : h->stats_own.p;
-    TIMED(h, KID_LM_LOCAL, (k_lm_local<<<nblocks_threads(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_k.p, h->e_sx.p, h->e_sy.p, stats_mine)));
-    k_set_header<<<1, 1, 0, h->stream>>>(stats_mine, L, (double)h->n_new_loc, 0.0);
+    if (h->world > 1) {
+        double* stats_mine = h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h);
+        TIMED(h, KID_LM_TOTALS, (k_lm_scan<true><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_k.p, h->e_wx.p, h->e_wy.p, nullptr, nullptr, nullptr, nullptr, nullptr, stats_mine, nullptr, nullptr)));
+        k_set_header<<<1, 1, 0, h->stream>>>(stats_mine, L, (double)h->n_new_loc, 0.0);
+    }
     HIPCHK(h, hipGetLastError());
     return ICM_OK;
 }
@@ -455,10 +472,16 @@ int icm_sweep_targets(icm_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     const int nlab = h->lact0 + (int)h->n_new_loc;
-    const double* all = h->world > 1 ? h->stats_all : h->stats_own.p;
-    TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
-    TIMED(h, KID_LM_CHAIN, (k_lm_chain<<<nblocks_threads(nlab), kBlock, 0, h->stream>>>(nlab, h->lm_off.p, h->sval.p, h->e_k.p, h->e_sx.p, h->e_sy.p, h->off_sx.p, h->off_sy.p, h->off_n.p, h->tgt_x.p, h->tgt_y.p)));
-    TIMED(h, KID_BEAM_TARGETS, (k_beam_targets<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->bloc.p, h->tgt_x.p, h->tgt_y.p, h->btx.p, h->bty.p)));
+    if (h->world > 1) {
+        TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
+        TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_k.p, h->e_wx.p, h->e_wy.p, h->off_sx.p, h->off_sy.p, h->off_n.p, h->tgt_x.p, h->tgt_y.p, nullptr, nullptr, nullptr)));
+    } else {
+        TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_k.p, h->e_wx.p, h->e_wy.p, nullptr, nullptr, nullptr, h->tgt_x.p, h->tgt_y.p, nullptr, h->y_raw.p, h->cnt_raw.p)));
+    }
+    if (h->form == 0)
+        TIMED(h, KID_POSE_MOMENTS, (k_pose_moments<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->ent_off.p, h->e_k.p, h->e_wrx.p, h->e_wry.p, h->tgt_x.p, h->tgt_y.p, h->pose_c.p, h->pose_m.p)));
+    if (h->assoc_kept)
+        TIMED(h, KID_BEAM_TARGETS, (k_beam_targets<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->bloc.p, h->tgt_x.p, h->tgt_y.p, h->btx.p, h->bty.p)));
     HIPCHK(h, hipGetLastError());
     return ICM_OK;
 }
@@ -472,16 +495,25 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     a.x = h->x; a.x0 = h->x0.p; a.odo = h->odo.p; a.u = h->u.p;
     a.T = (int)h->T; a.t_begin = (int)h->t_begin; a.nloc = (int)h->nloc;
     a.boff = h->boff.p; a.bx = h->bx.p; a.by = h->by.p; a.btx = h->btx.p; a.bty = h->bty.p;
+    a.per_beam = h->per_beam ? 1 : 0;
+    a.ent_off = h->ent_off.p; a.e_k = h->e_k.p; a.e_bx = h->e_bx.p; a.e_by = h->e_by.p;
+    a.tgt_x = h->tgt_x.p; a.tgt_y = h->tgt_y.p; a.pose_c = h->pose_c.p; a.pose_m = h->pose_m.p;
     a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
     a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
     a.diag = h->diag.p;
     if (schedule == ICM_SCHEDULE_SEQUENTIAL) {
         if (h->world != 1) FAIL(h, ICM_ERR_UNSUPPORTED, "the sequential (reference-order) schedule is one dependent chain and cannot be sharded");
-        TIMED(h, KID_SOLVE, (k_solve_sequential<<<1, kWave, 0, h->stream>>>(a)));
+        if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
+        else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_sequential<false><<<1, kWave, 0, h->stream>>>(a)));
+        else TIMED(h, KID_SOLVE, (k_solve_m_sequential<<<1, kWave, 0, h->stream>>>(a)));
     } else if (schedule == ICM_SCHEDULE_REDBLACK) {
         const int nw = (int)(h->nloc / 2 + 1);
-        if (colour == 1 || colour < 0) TIMED(h, KID_SOLVE, (k_solve_colour<<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, 1)));
-        if (colour == 0 || colour < 0) TIMED(h, KID_SOLVE, (k_solve_colour<<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, 0)));
+        for (int col = 1; col >= 0; --col) {
+            if (!(colour == col || colour < 0)) continue;
+            if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_colour<true><<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, col)));
+            else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_colour<false><<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, col)));
+            else TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_threads(nw), kBlock, 0, h->stream>>>(a, col)));
+        }
     } else {
         FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: unknown schedule");
     }
@@ -582,6 +614,7 @@ int icm_sweep(icm_handle* h, double* x, const double* x0, const double* map_in, 
 int icm_get_association(icm_handle* h, int32_t* labels, double* target_x, double* target_y) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_get_association: no sweep has run");
+    if (!h->assoc_kept) FAIL(h, ICM_ERR_ARG, "icm_get_association: enable icm_set_debug before the sweep");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t nz = (size_t)h->nnz;
@@ -707,6 +740,20 @@ int icm_last_stats(const icm_handle* h, int64_t* out4) {
     out4[1] = h->E;
     out4[2] = h->n_new_loc;
     out4[3] = h->lact_raw;
+    return ICM_OK;
+}
+
+int icm_set_debug(icm_handle* h, int on) {
+    if (!h) return ICM_ERR_ARG;
+    h->debug = on != 0;
+    return ICM_OK;
+}
+
+int icm_set_energy_form(icm_handle* h, int form) {
+    if (!h) return ICM_ERR_ARG;
+    if (form < 0 || form > 2) FAIL(h, ICM_ERR_ARG, "icm_set_energy_form: form must be 0, 1 or 2");
+    h->form = form;
+    h->per_beam = form == 1;
     return ICM_OK;
 }
 

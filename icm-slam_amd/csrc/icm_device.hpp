@@ -17,7 +17,8 @@ constexpr int kWave = 64;
 // entrepi (reference scripts/ICM_SLAM_tools.py:455-463): numpy mod (sign of the divisor),
 // then fold (pi, 2pi) down.  Result in [-pi, pi].
 __device__ __forceinline__ double wrap_pi(double a) {
-    double r = fmod(a, kTwoPi);
+    // fmod(a, b) == a exactly whenever |a| < b: the usual case, without fmod's division loop
+    double r = fabs(a) < kTwoPi ? a : fmod(a, kTwoPi);
     if (r < 0.0) r += kTwoPi;
     if (r > kPi) r -= kTwoPi;
     return r;
@@ -29,11 +30,27 @@ __device__ __forceinline__ double bcast_first(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// Butterfly sum over the 64 lanes: every lane ends with the same bits.
+// DPP move of a double (two dwords); lanes without a source read 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes, returned wave-uniform (same bits in every lane).  In-register DPP
+// tree: shifts by 1,2,4,8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 across
+// the rows; the total lands in lane 63 and is read back through scalar registers.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-    return bcast_first(v);
+    v += dpp_mov<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_mov<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_mov<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_mov<0x118, 0xF>(v);  // row_shr:8
+    v += dpp_mov<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 // Everything one pose solve needs besides its observation items.  Wave-uniform.
@@ -52,42 +69,135 @@ struct SolveCtx {
     double dt, R0, R1, R2, Q0, Q1, cte;
 };
 
-// Observation items of one pose: weight k, body-frame point b, world target y.
-// Plain beams have k = 1 (kw == nullptr).
+// Observation items of one pose.  Two forms of the same energy h(x):
+//   beams   (kw == nullptr): one item per kept beam, k = 1, b = the beam's body point;
+//   entries (kw != nullptr): one item per (pose, landmark) entry -- k beams that share the
+//           target y, b = their mean body point.  With r_j = rbar + R(b_j - bbar),
+//           sum_j r_j^T Q r_j = k rbar^T Q rbar + sum_j (R d_j)^T Q (R d_j), and the second
+//           term summed over the pose's entries is tr(R^T Q R C) with the pose's pooled
+//           within-entry scatter C = (cxx, cxy, cyy): exact algebra, x enters it only
+//           through theta and only when Q is anisotropic.
 struct Items {
     const double* __restrict__ bx;
     const double* __restrict__ by;
     const double* __restrict__ tx;
     const double* __restrict__ ty;
-    const double* __restrict__ kw;
-    double cst;  // x-independent remainder of h when items are aggregated moments
+    const int* __restrict__ kw;
+    double cxx, cxy, cyy;
     int n;
 };
 
-// h(x) = sum_i k_i (w_i - y_i)^T Q (w_i - y_i), w_i = p + Rot(th - pi/2) b_i
+// One item held in registers (entries form, n <= 64: lane i owns entry i).
+struct RegItem {
+    double k, bx, by, tx, ty;
+};
+
+__device__ __forceinline__ double scatter_term(const SolveCtx& c, const Items& it, double ct, double st) {
+    return ((c.Q0 * ct * ct + c.Q1 * st * st) * it.cxx + 2.0 * (ct * st) * (c.Q1 - c.Q0) * it.cxy) +
+           (c.Q0 * st * st + c.Q1 * ct * ct) * it.cyy;
+}
+
+// h(x) = sum_i k_i (w_i - y_i)^T Q (w_i - y_i) [+ scatter], w_i = p + Rot(th - pi/2) b_i
 // (reference scripts/ICM_ROS.py:171-200 with the body-frame points of filtrar_z's columns
 // 2:4; d*cos(ang + th - pi/2) is expanded with the rotation tras_rot_z uses,
 // scripts/ICM_SLAM_tools.py:476-479).
 __device__ __forceinline__ double obs_energy(const SolveCtx& c, const Items& it, double px,
                                              double py, double th, int lane) {
     const double a = th - kHalfPi;
-    const double ct = cos(a), st = sin(a);
+    double ct, st;
+    sincos(a, &st, &ct);
     double acc = 0.0;
     for (int j = lane; j < it.n; j += kWave) {
         const double bx = it.bx[j], by = it.by[j];
         const double dx = (px + (bx * ct - by * st)) - it.tx[j];
         const double dy = (py + (bx * st + by * ct)) - it.ty[j];
         double e = (dx * c.Q0) * dx + (dy * c.Q1) * dy;
-        if (it.kw) e *= it.kw[j];
+        if (it.kw) e *= (double)it.kw[j];
         acc += e;
     }
-    return wave_sum(acc) + it.cst;
+    acc = wave_sum(acc);
+    return it.kw ? acc + scatter_term(c, it, ct, st) : acc;
 }
 
-// fun_xn (two_sided) / fun_x (reference scripts/ICM_ROS.py:220-278), Appendix A.4.
-__device__ __forceinline__ double pose_energy(const SolveCtx& c, const Items& it, double px,
-                                              double py, double th, int lane) {
-    const double hh = obs_energy(c, it, px, py, th, lane);
+// Same energy with the (<= 64) entries of the pose held one per lane in registers.
+__device__ __forceinline__ double obs_energy_reg(const SolveCtx& c, const Items& it, const RegItem& r,
+                                                 double px, double py, double th) {
+    const double a = th - kHalfPi;
+    double ct, st;
+    sincos(a, &st, &ct);
+    const double dx = (px + (r.bx * ct - r.by * st)) - r.tx;
+    const double dy = (py + (r.bx * st + r.by * ct)) - r.ty;
+    const double e = ((dx * c.Q0) * dx + (dy * c.Q1) * dy) * r.k;
+    return wave_sum(e) + scatter_term(c, it, ct, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Moment form of h(x): the default in the pose solves.
+// Expand every entry's residual around the pose's previous-sweep value (p_o, th_o), the pose
+// the beams were projected with in phase A.  With w = Rot(th_o - pi/2) bbar (the entry's mean
+// offset in the world frame), r0 = p_o + w - y (its residual there), dp = p - p_o,
+// d = th - th_o, alpha = cos d - 1, beta = sin d, J = [[0,-1],[1,0]]:
+//     r(x) = p + Rot(th - pi/2) bbar - y = r0 + dp + alpha w + beta J w            (exact)
+// so h(x) = sum_e k r^T Q r (+ the scatter term) is a quadratic form in (dp, alpha, beta)
+// whose 14 coefficients are sums over the pose's entries.  Every term is O(residual): unlike
+// the expansion about the origin nothing cancels, so the form is as accurate as the direct
+// sum, but an evaluation costs ~40 flops and no memory access -- which lets ONE LANE solve a
+// pose (64 poses per wavefront, no cross-lane reduction).
+// ---------------------------------------------------------------------------------------
+struct PoseMoments {
+    double S, Swx, Swy, Srx, Sry, Swxx, Swyy, Swxy, Swxrx, Swyrx, Swxry, Swyry, Srxx, Sryy;
+    double cxx, cxy, cyy;      // pooled within-entry scatter (body frame)
+    double pox, poy, co, so;   // expansion point: p_o, cos/sin th_o
+};
+constexpr int kMomentCount = 14;
+
+__device__ __forceinline__ double moments_energy(const SolveCtx& c, const PoseMoments& m, double px, double py,
+                                                 double cth, double sth) {
+    const double dx = px - m.pox, dy = py - m.poy;
+    const double sd = sth * m.co - cth * m.so;   // sin(th - th_o)
+    const double cd = cth * m.co + sth * m.so;   // cos(th - th_o)
+    const double den = 1.0 + cd;
+    const double al = den > 1e-3 ? -(sd * sd) / den : cd - 1.0;  // cos d - 1 without cancellation
+    const double be = sd;
+    const double X = (((m.S * dx) * dx + (al * al) * m.Swxx) + ((be * be) * m.Swyy + m.Srxx)) +
+                     2.0 * ((dx * ((al * m.Swx - be * m.Swy) + m.Srx) + al * (m.Swxrx - be * m.Swxy)) - be * m.Swyrx);
+    const double Y = (((m.S * dy) * dy + (al * al) * m.Swyy) + ((be * be) * m.Swxx + m.Sryy)) +
+                     2.0 * ((dy * ((al * m.Swy + be * m.Swx) + m.Sry) + al * (m.Swyry + be * m.Swxy)) + be * m.Swxry);
+    // scatter term with cos(th - pi/2) = sin th, sin(th - pi/2) = -cos th
+    const double ct = sth, st = -cth;
+    const double sc = ((c.Q0 * ct * ct + c.Q1 * st * st) * m.cxx + 2.0 * (ct * st) * (c.Q1 - c.Q0) * m.cxy) +
+                      (c.Q0 * st * st + c.Q1 * ct * ct) * m.cyy;
+    return (c.Q0 * X + c.Q1 * Y) + sc;
+}
+
+// fun_xn / fun_x with h in moment form; one sincos per evaluation.
+__device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const PoseMoments& m, double px, double py,
+                                                      double th) {
+    double cth, sth;
+    sincos(th, &sth, &cth);
+    const double hh = moments_energy(c, m, px, py, cth, sth);
+    const double r0 = px - c.gax, r1 = py - c.gay, r2 = wrap_pi(th - c.gat);
+    const double prevR = ((r0 * c.R0) * r0 + (r1 * c.R1) * r1) + (r2 * c.R2) * r2;
+    const double dax = px - c.xax, day = py - c.xay;
+    const double q0 = c.o1x - (c.ca * dax + c.sa * day);
+    const double q1 = c.o1y - (-c.sa * dax + c.ca * day);
+    const double q2 = wrap_pi((c.o1t - th) + c.xat);
+    const double prevO = c.cte * ((q0 * q0 + q1 * q1) + q2 * q2);
+    if (!c.two_sided) return (prevR + hh) + prevO;
+    const double gx = px + c.dt * (cth * c.v), gy = py + c.dt * (sth * c.v), gt = th + c.dt * c.w;
+    const double s0 = gx - c.xpx, s1 = gy - c.xpy, s2 = wrap_pi(gt - c.xpt);
+    const double nextR = ((s0 * c.R0) * s0 + (s1 * c.R1) * s1) + (s2 * c.R2) * s2;
+    const double ex = c.xpx - px, ey = c.xpy - py;
+    const double p0 = c.o2x - (cth * ex + sth * ey);
+    const double p1 = c.o2y - (-sth * ex + cth * ey);
+    const double p2 = wrap_pi((c.o2t - c.xpt) + th);
+    const double nextO = c.cte * ((p0 * p0 + p1 * p1) + p2 * p2);
+    return (((nextR + nextO) + prevR) + hh) + prevO;
+}
+
+// fun_xn (two_sided) / fun_x (reference scripts/ICM_ROS.py:220-278), Appendix A.4, given
+// the observation energy hh = h(x).
+__device__ __forceinline__ double pose_energy_with(const SolveCtx& c, double hh, double px, double py, double th) {
     // prev(x; a)
     const double r0 = px - c.gax, r1 = py - c.gay, r2 = wrap_pi(th - c.gat);
     const double prevR = ((r0 * c.R0) * r0 + (r1 * c.R1) * r1) + (r2 * c.R2) * r2;
@@ -98,7 +208,8 @@ __device__ __forceinline__ double pose_energy(const SolveCtx& c, const Items& it
     const double prevO = c.cte * ((q0 * q0 + q1 * q1) + q2 * q2);
     if (!c.two_sided) return (prevR + hh) + prevO;
     // next(x; b)
-    const double cth = cos(th), sth = sin(th);
+    double cth, sth;
+    sincos(th, &sth, &cth);
     const double gx = px + c.dt * (cth * c.v), gy = py + c.dt * (sth * c.v), gt = th + c.dt * c.w;
     const double s0 = gx - c.xpx, s1 = gy - c.xpy, s2 = wrap_pi(gt - c.xpt);
     const double nextR = ((s0 * c.R0) * s0 + (s1 * c.R1) * s1) + (s2 * c.R2) * s2;
@@ -108,6 +219,11 @@ __device__ __forceinline__ double pose_energy(const SolveCtx& c, const Items& it
     const double p2 = wrap_pi((c.o2t - c.xpt) + th);
     const double nextO = c.cte * ((p0 * p0 + p1 * p1) + p2 * p2);
     return (((nextR + nextO) + prevR) + hh) + prevO;
+}
+
+__device__ __forceinline__ double pose_energy(const SolveCtx& c, const Items& it, double px,
+                                              double py, double th, int lane) {
+    return pose_energy_with(c, obs_energy(c, it, px, py, th, lane), px, py, th);
 }
 
 // Fill the x-independent parts of the context for pose t.
@@ -171,70 +287,93 @@ __device__ __forceinline__ double amax3(const Vtx& a, const Vtx& b) {
 // rho=1 chi=2 psi=sigma=0.5, xatol=1e-3 AND fatol=1e-4, maxiter=maxfun=600, initial simplex
 // x0 with one coordinate *1.05 (0.00025 if it is exactly 0), one stable sort per iteration.
 // A function call beyond maxfun aborts the iteration like SciPy's _MaxFuncCallError.
+// Written as a state machine around ONE call site of f, so the (large) energy body exists
+// once in the kernel instead of once per simplex move.
 // out = {x, y, theta, f, nit, nfev}.
 template <class F>
 __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double st, double out[6]) {
     const int maxfun = 600, maxiter = 600;
     const double xatol = 1e-3, fatol = 1e-4;
     const double grow = 1 + 0.05;
+    enum { S_INIT, S_REFLECT, S_EXPAND, S_OUTSIDE, S_INSIDE, S_SHRINK };
     Vtx v0{sx, sy, st, 0.0};
     Vtx v1{sx != 0.0 ? grow * sx : 0.00025, sy, st, 0.0};
     Vtx v2{sx, sy != 0.0 ? grow * sy : 0.00025, st, 0.0};
     Vtx v3{sx, sy, st != 0.0 ? grow * st : 0.00025, 0.0};
-    v0.f = f(v0.x, v0.y, v0.t);
-    v1.f = f(v1.x, v1.y, v1.t);
-    v2.f = f(v2.x, v2.y, v2.t);
-    v3.f = f(v3.x, v3.y, v3.t);
-    int nfev = 4, it = 1;
-    sort4(v0, v1, v2, v3);
-    while (nfev < maxfun && it < maxiter) {
+    Vtx r{0, 0, 0, 0}, cur = v0;
+    double bx = 0, by = 0, bt = 0;
+    int state = S_INIT, idx = 0, nfev = 0, it = 1;
+    for (;;) {
+        if (nfev >= maxfun) {  // only reachable inside an iteration: abort it, sort, stop
+            sort4(v0, v1, v2, v3);
+            break;
+        }
+        cur.f = f(cur.x, cur.y, cur.t);
+        ++nfev;
+        bool end_iter = false, shrink = false;
+        if (state == S_INIT || state == S_SHRINK) {
+            if (idx == 0) v0.f = cur.f; else if (idx == 1) v1.f = cur.f; else if (idx == 2) v2.f = cur.f; else v3.f = cur.f;
+            ++idx;
+            if (idx < 4) {
+                if (state == S_SHRINK) {  // sim[j] = sim[0] + sigma (sim[j] - sim[0]), then evaluate it
+                    if (idx == 2) {
+                        v2.x = v0.x + 0.5 * (v2.x - v0.x); v2.y = v0.y + 0.5 * (v2.y - v0.y); v2.t = v0.t + 0.5 * (v2.t - v0.t);
+                    } else {
+                        v3.x = v0.x + 0.5 * (v3.x - v0.x); v3.y = v0.y + 0.5 * (v3.y - v0.y); v3.t = v0.t + 0.5 * (v3.t - v0.t);
+                    }
+                }
+                if (idx == 1) cur = v1; else if (idx == 2) cur = v2; else cur = v3;
+                continue;
+            }
+            if (state == S_SHRINK) end_iter = true;
+            else sort4(v0, v1, v2, v3);
+        } else if (state == S_REFLECT) {
+            r = cur;
+            if (r.f < v0.f) {
+                cur = Vtx{3 * bx - 2 * v3.x, 3 * by - 2 * v3.y, 3 * bt - 2 * v3.t, 0.0};
+                state = S_EXPAND;
+                continue;
+            } else if (r.f < v2.f) {
+                v3 = r;
+                end_iter = true;
+            } else if (r.f < v3.f) {
+                cur = Vtx{1.5 * bx - 0.5 * v3.x, 1.5 * by - 0.5 * v3.y, 1.5 * bt - 0.5 * v3.t, 0.0};
+                state = S_OUTSIDE;
+                continue;
+            } else {
+                cur = Vtx{0.5 * bx + 0.5 * v3.x, 0.5 * by + 0.5 * v3.y, 0.5 * bt + 0.5 * v3.t, 0.0};
+                state = S_INSIDE;
+                continue;
+            }
+        } else if (state == S_EXPAND) {
+            v3 = (cur.f < r.f) ? cur : r;
+            end_iter = true;
+        } else if (state == S_OUTSIDE) {
+            if (cur.f <= r.f) { v3 = cur; end_iter = true; } else shrink = true;
+        } else {  // S_INSIDE
+            if (cur.f < v3.f) { v3 = cur; end_iter = true; } else shrink = true;
+        }
+        if (shrink) {
+            v1.x = v0.x + 0.5 * (v1.x - v0.x); v1.y = v0.y + 0.5 * (v1.y - v0.y); v1.t = v0.t + 0.5 * (v1.t - v0.t);
+            cur = v1;
+            idx = 1;
+            state = S_SHRINK;
+            continue;
+        }
+        if (end_iter) {
+            ++it;
+            sort4(v0, v1, v2, v3);
+        }
+        // top of SciPy's while loop
+        if (!(nfev < maxfun && it < maxiter)) break;
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
         if (dx <= xatol && df <= fatol) break;
-        const double bx = ((v0.x + v1.x) + v2.x) / 3.0;
-        const double by = ((v0.y + v1.y) + v2.y) / 3.0;
-        const double bt = ((v0.t + v1.t) + v2.t) / 3.0;
-        do {
-            Vtx r{2 * bx - v3.x, 2 * by - v3.y, 2 * bt - v3.t, 0.0};
-            if (nfev >= maxfun) break;
-            r.f = f(r.x, r.y, r.t);
-            ++nfev;
-            bool shrink = false;
-            if (r.f < v0.f) {
-                Vtx e{3 * bx - 2 * v3.x, 3 * by - 2 * v3.y, 3 * bt - 2 * v3.t, 0.0};
-                if (nfev >= maxfun) break;
-                e.f = f(e.x, e.y, e.t);
-                ++nfev;
-                v3 = (e.f < r.f) ? e : r;
-            } else if (r.f < v2.f) {
-                v3 = r;
-            } else if (r.f < v3.f) {
-                Vtx c{1.5 * bx - 0.5 * v3.x, 1.5 * by - 0.5 * v3.y, 1.5 * bt - 0.5 * v3.t, 0.0};
-                if (nfev >= maxfun) break;
-                c.f = f(c.x, c.y, c.t);
-                ++nfev;
-                if (c.f <= r.f) v3 = c; else shrink = true;
-            } else {
-                Vtx c{0.5 * bx + 0.5 * v3.x, 0.5 * by + 0.5 * v3.y, 0.5 * bt + 0.5 * v3.t, 0.0};
-                if (nfev >= maxfun) break;
-                c.f = f(c.x, c.y, c.t);
-                ++nfev;
-                if (c.f < v3.f) v3 = c; else shrink = true;
-            }
-            if (shrink) {
-                v1.x = v0.x + 0.5 * (v1.x - v0.x); v1.y = v0.y + 0.5 * (v1.y - v0.y); v1.t = v0.t + 0.5 * (v1.t - v0.t);
-                if (nfev >= maxfun) break;
-                v1.f = f(v1.x, v1.y, v1.t); ++nfev;
-                v2.x = v0.x + 0.5 * (v2.x - v0.x); v2.y = v0.y + 0.5 * (v2.y - v0.y); v2.t = v0.t + 0.5 * (v2.t - v0.t);
-                if (nfev >= maxfun) break;
-                v2.f = f(v2.x, v2.y, v2.t); ++nfev;
-                v3.x = v0.x + 0.5 * (v3.x - v0.x); v3.y = v0.y + 0.5 * (v3.y - v0.y); v3.t = v0.t + 0.5 * (v3.t - v0.t);
-                if (nfev >= maxfun) break;
-                v3.f = f(v3.x, v3.y, v3.t); ++nfev;
-            }
-            ++it;
-        } while (0);
-        sort4(v0, v1, v2, v3);
+        bx = ((v0.x + v1.x) + v2.x) / 3.0;
+        by = ((v0.y + v1.y) + v2.y) / 3.0;
+        bt = ((v0.t + v1.t) + v2.t) / 3.0;
+        cur = Vtx{2 * bx - v3.x, 2 * by - v3.y, 2 * bt - v3.t, 0.0};
+        state = S_REFLECT;
     }
     out[0] = v0.x; out[1] = v0.y; out[2] = v0.t; out[3] = v0.f;
     out[4] = (double)it; out[5] = (double)nfev;

@@ -2,19 +2,21 @@
 //
 // Phase map:
 //   once      k_prefilter      filtrar_z for every scan            -> kept beams, CSR by pose
-//   phase A   k_associate      project + gated nearest landmark     -> label per kept beam
-//             k_group          per pose: distinct labels, ordered sums of world points
-//             k_compact        entries to pose-major compact arrays, fresh ids for new landmarks
-//             (radix sort by label, rocPRIM)                        -> CSR by landmark
-//   phase B/D k_lm_local       per-landmark local sufficient statistics (sum x, sum y, n)
+//   phase A   k_assoc_group    project + gated nearest landmark + per-pose grouping: one
+//                              (pose, landmark) ENTRY per distinct label of the scan with
+//                              the count and the sums of the body / world points
+//             k_scan_*         entry offsets, ranks of poses that create a landmark
+//             k_compact        entries -> pose-major compact arrays, fresh ids for new landmarks
+//             (radix sort of the entry ids by label, rocPRIM)      -> CSR by landmark
+//   phase B/D k_lm_scan        one wave per landmark: time-ordered prefix of its entries
+//                              -> running-mean target of every entry, landmark totals
 //             k_stats_prefix   totals + exclusive prefix over lower ranks (after all-gather)
-//             k_lm_chain       per-landmark time-ordered prefix -> running-mean targets
-//             k_beam_targets   target per kept beam
-//   phase C   k_solve          one wavefront per pose: Nelder-Mead on the conditional energy
+//   phase C   k_solve_*        one wavefront per pose: Nelder-Mead on the conditional energy,
+//                              the pose's entries held one per lane in registers
 //
-// Mapping rule everywhere: one wavefront (64 lanes) per pose, lanes stride over the pose's
-// kept beams / entries; 256-thread workgroups = 4 poses.  No MFMA: there is no dense
-// contraction on this path.
+// Mapping rule everywhere: one wavefront (64 lanes) per pose (or per landmark), lanes stride
+// over the pose's kept beams / entries; 256-thread workgroups = 4 poses.  No MFMA: there is
+// no dense contraction on this path.
 #include <hip/hip_runtime.h>
 
 #include "icm_device.hpp"
@@ -23,12 +25,120 @@ namespace icm {
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kGroupCap = 256;  // distinct landmarks one scan may touch
+constexpr int kHash = 256;      // LDS hash slots per pose (distinct landmarks of one scan)
+constexpr int kGroupCap = 192;  // ... of which at most this many may be used
+constexpr int kEmpty = (int)0x80000000;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
 __device__ __forceinline__ int prefix_count(unsigned long long mask, int lane) {
     return __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// ---------------------------------------------------------------------------------------
+// Two-level exclusive scan of two int arrays at once (entry counts, new-landmark flags).
+// k_scan_tiles: 1024-element tiles, local exclusive scan + tile totals;
+// k_scan_fix:   adds the totals of the preceding tiles; out[n] = grand total.
+// ---------------------------------------------------------------------------------------
+constexpr int kScanTile = 1024;
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const int* __restrict__ a, const int* __restrict__ b,
+                                                       int* __restrict__ oa, int* __restrict__ ob,
+                                                       int* __restrict__ tot, int n) {
+    __shared__ int wa[kWavesPerBlock], wb[kWavesPerBlock];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+    int va[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        va[i] = base + i < n ? a[base + i] : 0;
+        vb[i] = base + i < n ? b[base + i] : 0;
+    }
+    int sa = va[0] + va[1] + va[2] + va[3], sb = vb[0] + vb[1] + vb[2] + vb[3];
+    int ia = sa, ib = sb;  // inclusive scan over the wave
+    const int lane = lane_id(), w = wave_in_block();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int ua = __shfl_up(ia, d, kWave), ub = __shfl_up(ib, d, kWave);
+        if (lane >= d) {
+            ia += ua;
+            ib += ub;
+        }
+    }
+    if (lane == kWave - 1) {
+        wa[w] = ia;
+        wb[w] = ib;
+    }
+    __syncthreads();
+    int pa = 0, pb = 0;
+    for (int q = 0; q < w; ++q) {
+        pa += wa[q];
+        pb += wb[q];
+    }
+    int ea = pa + ia - sa, eb = pb + ib - sb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (base + i < n) {
+            oa[base + i] = ea;
+            ob[base + i] = eb;
+        }
+        ea += va[i];
+        eb += vb[i];
+    }
+    if (threadIdx.x == kBlock - 1) {
+        tot[2 * blockIdx.x] = pa + ia;
+        tot[2 * blockIdx.x + 1] = pb + ib;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_fix(int* __restrict__ oa, int* __restrict__ ob,
+                                                     const int* __restrict__ tot, int n, int ntiles) {
+    __shared__ int ra[kBlock], rb[kBlock];
+    // sum of the totals of all tiles before this one (and, for the last block, the grand total)
+    const int mine = blockIdx.x;
+    int sa = 0, sb = 0, ga = 0, gb = 0;
+    for (int q = threadIdx.x; q < ntiles; q += kBlock) {
+        const int ta = tot[2 * q], tb = tot[2 * q + 1];
+        if (q < mine) {
+            sa += ta;
+            sb += tb;
+        }
+        ga += ta;
+        gb += tb;
+    }
+    ra[threadIdx.x] = sa;
+    rb[threadIdx.x] = sb;
+    __syncthreads();
+    for (int d = kBlock / 2; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+            ra[threadIdx.x] += ra[threadIdx.x + d];
+            rb[threadIdx.x] += rb[threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    const int offa = ra[0], offb = rb[0];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (base + i < n) {
+            oa[base + i] += offa;
+            ob[base + i] += offb;
+        }
+    if (mine == ntiles - 1) {
+        __syncthreads();
+        ra[threadIdx.x] = ga;
+        rb[threadIdx.x] = gb;
+        __syncthreads();
+        for (int d = kBlock / 2; d > 0; d >>= 1) {
+            if (threadIdx.x < d) {
+                ra[threadIdx.x] += ra[threadIdx.x + d];
+                rb[threadIdx.x] += rb[threadIdx.x + d];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            oa[n] = ra[0];
+            ob[n] = rb[0];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -70,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_prefilter(const double* __restrict__
                                                       double rmax, double thr, int* __restrict__ nkept,
                                                       const int* __restrict__ boff, int* __restrict__ bk,
                                                       double* __restrict__ bd, double* __restrict__ bx,
-                                                      double* __restrict__ by) {
+                                                      double* __restrict__ by, double* __restrict__ pose_s2) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int w = wave_in_block(), lane = lane_id();
     const int t = blockIdx.x * kWavesPerBlock + w;
@@ -104,10 +214,12 @@ __global__ __launch_bounds__(kBlock) void k_prefilter(const double* __restrict__
     __builtin_amdgcn_wave_barrier();
     if (cnt <= 1) {
         if (!WRITE && lane == 0) nkept[t] = 0;
+        if (WRITE && lane == 0) pose_s2[3 * (size_t)t] = pose_s2[3 * (size_t)t + 1] = pose_s2[3 * (size_t)t + 2] = 0.0;
         return;
     }
     // isolated-beam rejection: nearest other in-range beam, exact zeros count as 100
     int kept = 0;
+    double sxx = 0.0, sxy = 0.0, syy = 0.0;  // sum of b b^T over the kept beams (pose constant)
     for (int base = 0; base < cnt; base += kWave) {
         const int i = base + lane;
         bool keep = false;
@@ -129,10 +241,23 @@ __global__ __launch_bounds__(kBlock) void k_prefilter(const double* __restrict__
             bd[p] = lm[i];
             bx[p] = lpx[i];
             by[p] = lpy[i];
+            sxx += lpx[i] * lpx[i];
+            sxy += lpx[i] * lpy[i];
+            syy += lpy[i] * lpy[i];
         }
         kept += __popcll(mask);
     }
     if (!WRITE && lane == 0) nkept[t] = kept;
+    if (WRITE) {
+        sxx = wave_sum(sxx);
+        sxy = wave_sum(sxy);
+        syy = wave_sum(syy);
+        if (lane == 0) {
+            pose_s2[3 * (size_t)t] = sxx;
+            pose_s2[3 * (size_t)t + 1] = sxy;
+            pose_s2[3 * (size_t)t + 2] = syy;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -167,44 +292,29 @@ __device__ __forceinline__ void pose_of(const double* __restrict__ x, const doub
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_associate(const double* __restrict__ x, const double* __restrict__ x0,
-                                                      int t_begin, int nloc, const int* __restrict__ boff,
-                                                      const double* __restrict__ bx, const double* __restrict__ by,
-                                                      GridView g, double thr, int* __restrict__ label) {
-    const int lane = lane_id();
-    const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
-    if (tl >= nloc) return;
-    const int j0 = boff[tl], j1 = boff[tl + 1];
-    if (j0 == j1) return;
-    double px, py, th;
-    pose_of(x, x0, t_begin + tl, px, py, th);
-    const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
-    for (int j = j0 + lane; j < j1; j += kWave) {
-        const double bxx = bx[j], byy = by[j];
-        const double wx = (bxx * ct - byy * st) + px;
-        const double wy = (bxx * st + byy * ct) + py;
-        const int cx = grid_cell(wx, g.gx0, g.inv, g.nx), cy = grid_cell(wy, g.gy0, g.inv, g.ny);
-        const int c0 = max(cx - 1, 0), c1 = min(cx + 1, g.nx - 1);
-        double best = __builtin_huge_val();
-        int bid = -1;
-        for (int ry = max(cy - 1, 0); ry <= min(cy + 1, g.ny - 1); ++ry) {
-            const int p0 = g.cell_start[ry * g.nx + c0], p1 = g.cell_start[ry * g.nx + c1 + 1];
-            for (int p = p0; p < p1; ++p) {
-                const double dx = g.lx[p] - wx, dy = g.ly[p] - wy;
-                const double d = sqrt(dx * dx + dy * dy);
-                const int id = g.id[p];
-                if (d < best || (d == best && id < bid)) {
-                    best = d;
-                    bid = id;
-                }
+__device__ __forceinline__ int assoc_grid(const GridView& g, double wx, double wy, double thr) {
+    const int cx = grid_cell(wx, g.gx0, g.inv, g.nx), cy = grid_cell(wy, g.gy0, g.inv, g.ny);
+    const int c0 = max(cx - 1, 0), c1 = min(cx + 1, g.nx - 1);
+    double best = __builtin_huge_val();
+    int bid = -1;
+    for (int ry = max(cy - 1, 0); ry <= min(cy + 1, g.ny - 1); ++ry) {
+        const int p0 = g.cell_start[ry * g.nx + c0], p1 = g.cell_start[ry * g.nx + c1 + 1];
+        for (int p = p0; p < p1; ++p) {
+            const double dx = g.lx[p] - wx, dy = g.ly[p] - wy;
+            const double d = sqrt(dx * dx + dy * dy);
+            const int id = g.id[p];
+            if (d < best || (d == best && id < bid)) {
+                best = d;
+                bid = id;
             }
         }
-        label[j] = (bid >= 0 && !(best > thr)) ? bid : -1;
     }
+    return (bid >= 0 && !(best > thr)) ? bid : -1;
 }
 
-// Brute-force form of the same association (all K landmarks, LDS-tiled table): the literal
-// cdist/argmin of the reference.  Used to cross-check the grid search on the GPU.
+// Brute-force form of the same association (all K landmarks, table tiled through LDS): the
+// literal cdist/argmin of the reference.  Writes labels only; used to cross-check the grid
+// search on the GPU (k_assoc_group<PRELABEL> then consumes the labels).
 __global__ __launch_bounds__(kBlock) void k_associate_brute(const double* __restrict__ x, const double* __restrict__ x0,
                                                             int t_begin, int nloc, const int* __restrict__ boff,
                                                             const double* __restrict__ bx, const double* __restrict__ by,
@@ -212,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_associate_brute(const double* __rest
                                                             int K, double thr, int* __restrict__ label) {
     constexpr int TILE = 1024;
     __shared__ double sx[TILE], sy[TILE];
+    __shared__ int s_maxit;
     const int lane = lane_id();
     const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
     const bool live = tl < nloc;
@@ -224,13 +335,11 @@ __global__ __launch_bounds__(kBlock) void k_associate_brute(const double* __rest
     }
     const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
     const int iters = (j1 - j0 + kWave - 1) / kWave;
-    int maxit = iters;  // block-uniform trip count so every wave reaches the barriers
-    __shared__ int s_maxit;
     if (threadIdx.x == 0) s_maxit = 0;
     __syncthreads();
-    atomicMax(&s_maxit, iters);
+    atomicMax(&s_maxit, iters);  // block-uniform trip count: every wave reaches the barriers
     __syncthreads();
-    maxit = s_maxit;
+    const int maxit = s_maxit;
     for (int itn = 0; itn < maxit; ++itn) {
         const int j = j0 + itn * kWave + lane;
         const bool on = live && j < j1;
@@ -264,35 +373,42 @@ __global__ __launch_bounds__(kBlock) void k_associate_brute(const double* __rest
 }
 
 // ---------------------------------------------------------------------------------------
-// Per pose: distinct labels of the scan (label -1 = the scan's gated-out beams, which the
-// reference folds into ONE new landmark) with the ordered sum of
-// their world points and the count -- the per-scan terms of the running mean
-// (scripts/ICM_SLAM_tools.py:184-195).  Entries are staged at the front of the pose's beam
-// range; bloc[j] = entry of beam j within its pose.
+// Fused phase A: association + per-pose grouping.  For every distinct label of the scan
+// (label -1 = the scan's gated-out beams, which the reference folds into ONE new landmark,
+// SURVEY Appendix B.1) one ENTRY: the beam count k and the sums of the body-frame points --
+// the sufficient statistics of both the running-mean update (scripts/ICM_SLAM_tools.py:184-195:
+// sum of world points = k p + R sum b) and of the pose energy (icm_device.hpp, Items).
+//
+// Beams arrive sorted by bearing, so equal labels form runs: a wave-level segmented scan
+// reduces each run, and the run tails fold their totals into a 256-slot LDS hash table keyed
+// by label (linear probing, claimed with ds_cmpst).  Deterministic: runs are folded chunk
+// by chunk, and two runs of one label inside a chunk are folded in lane order.
+// Entries are staged at the front of the pose's beam range, in slot order.
+//   PRELABEL: labels come from `label` (brute-force cross-check) instead of the grid search
+//   DEBUG:    also write label[] and the beam -> entry map bloc[]
 // ---------------------------------------------------------------------------------------
-struct GroupScratch {
-    int tlab[kGroupCap];
-    int tk[kGroupCap];
-    double tsx[kGroupCap];
-    double tsy[kGroupCap];
-    double cwx[kWave];
-    double cwy[kWave];
-    int ce[kWave];
+struct PoseTable {
+    int key[kHash];
+    int cnt[kHash];
+    int owner[kHash];
+    double sx[kHash];
+    double sy[kHash];
 };
 
-__global__ __launch_bounds__(kBlock) void k_group(const double* __restrict__ x, const double* __restrict__ x0,
-                                                  int t_begin, int nloc, const int* __restrict__ boff,
-                                                  const double* __restrict__ bx, const double* __restrict__ by,
-                                                  const int* __restrict__ label, int* __restrict__ bloc,
-                                                  int* __restrict__ st_label, int* __restrict__ st_k,
-                                                  double* __restrict__ st_sx, double* __restrict__ st_sy,
-                                                  int* __restrict__ nent_out, int* __restrict__ isnew_out,
-                                                  int* __restrict__ flags) {
-    __shared__ GroupScratch scratch[kWavesPerBlock];
+template <bool PRELABEL, bool DEBUG>
+__global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
+                                                        int t_begin, int nloc, const int* __restrict__ boff,
+                                                        const double* __restrict__ bx, const double* __restrict__ by,
+                                                        GridView g, double thr, int* __restrict__ label,
+                                                        int* __restrict__ bloc, int* __restrict__ st_label,
+                                                        int* __restrict__ st_k, double* __restrict__ st_sbx,
+                                                        double* __restrict__ st_sby, int* __restrict__ nent_out,
+                                                        int* __restrict__ isnew_out, int* __restrict__ flags) {
+    __shared__ PoseTable tables[kWavesPerBlock];
     const int lane = lane_id();
     const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (tl >= nloc) return;
-    GroupScratch& s = scratch[wave_in_block()];
+    PoseTable& T = tables[wave_in_block()];
     const int j0 = boff[tl], j1 = boff[tl + 1];
     if (j0 == j1) {
         if (lane == 0) {
@@ -301,116 +417,188 @@ __global__ __launch_bounds__(kBlock) void k_group(const double* __restrict__ x, 
         }
         return;
     }
+    for (int s = lane; s < kHash; s += kWave) {
+        T.key[s] = kEmpty;
+        T.cnt[s] = 0;
+        T.sx[s] = 0.0;
+        T.sy[s] = 0.0;
+    }
     double px, py, th;
     pose_of(x, x0, t_begin + tl, px, py, th);
     const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
     int nent = 0;
     bool overflow = false;
-    for (int base = j0; base < j1; base += kWave) {
+    __builtin_amdgcn_wave_barrier();
+    for (int base = j0; base < j1 && !overflow; base += kWave) {
         const int j = base + lane;
         const bool valid = j < j1;
         const int cn = min(kWave, j1 - base);
         int lab = -2;
-        double wx = 0, wy = 0;
+        double bxx = 0.0, byy = 0.0;
         if (valid) {
-            lab = label[j];
-            wx = (bx[j] * ct - by[j] * st) + px;
-            wy = (bx[j] * st + by[j] * ct) + py;
+            bxx = bx[j];
+            byy = by[j];
+            if (PRELABEL) {
+                lab = label[j];
+            } else {
+                const double wx = (bxx * ct - byy * st) + px;
+                const double wy = (bxx * st + byy * ct) + py;
+                lab = assoc_grid(g, wx, wy, thr);
+                if (DEBUG) label[j] = lab;
+            }
         }
-        // look the label up among the entries found so far
-        int e = -1;
-        for (int q = 0; q < nent; ++q)
-            if (s.tlab[q] == lab) e = q;
-        // append the labels that are new in this chunk, in beam order
-        bool pend = valid && e < 0;
-        unsigned long long m;
-        while ((m = __ballot(pend)) != 0ull) {
-            const int l0 = __ffsll((long long)m) - 1;
-            const int lab0 = __shfl(lab, l0, kWave);
-            if (nent >= kGroupCap) {
-                overflow = true;
-                pend = false;
-                continue;
-            }
-            if (lane == l0) {
-                s.tlab[nent] = lab0;
-                s.tk[nent] = 0;
-                s.tsx[nent] = 0.0;
-                s.tsy[nent] = 0.0;
-            }
-            if (pend && lab == lab0) {
-                e = nent;
-                pend = false;
-            }
-            ++nent;
-        }
-        s.cwx[lane] = wx;
-        s.cwy[lane] = wy;
-        s.ce[lane] = valid ? e : -3;
-        __builtin_amdgcn_wave_barrier();
-        // ordered accumulation: every member walks the chunk in beam order, the first
-        // member of each entry writes the result back
-        if (valid && e >= 0) {
-            double sx = s.tsx[e], sy = s.tsy[e];
-            int kk = s.tk[e];
-            bool leader = true;
-            for (int q = 0; q < cn; ++q) {
-                if (s.ce[q] == e) {
-                    sx += s.cwx[q];
-                    sy += s.cwy[q];
-                    ++kk;
-                    if (q < lane) leader = false;
+        // runs of equal labels: head flags, segmented inclusive scan of (1, bx, by)
+        const int prev = __shfl_up(lab, 1, kWave);
+        const bool head = valid && (lane == 0 || prev != lab);
+        int f = head ? 1 : 0, c = valid ? 1 : 0;
+        double ax = bxx, ay = byy;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int fu = __shfl_up(f, d, kWave), cu = __shfl_up(c, d, kWave);
+            const double xu = __shfl_up(ax, d, kWave), yu = __shfl_up(ay, d, kWave);
+            if (lane >= d) {
+                if (!f) {
+                    c += cu;
+                    ax += xu;
+                    ay += yu;
                 }
+                f |= fu;
             }
-            __builtin_amdgcn_wave_barrier();
-            if (leader) {
-                s.tsx[e] = sx;
-                s.tsy[e] = sy;
-                s.tk[e] = kk;
-            }
-            bloc[j] = e;
-        } else if (valid) {
-            bloc[j] = 0;
         }
+        const int nexthead = __shfl_down(head ? 1 : 0, 1, kWave);
+        const bool tail = valid && (lane == cn - 1 || nexthead);
+        // run tails claim / find the slot of their label
+        int slot = 0;
+        bool inserted = false;
+        if (tail) {
+            slot = (int)(((unsigned)lab * 2654435761u) >> 24);
+            for (;;) {
+                const int k = T.key[slot];
+                if (k == lab) break;
+                if (k == kEmpty) {
+                    const int old = atomicCAS(&T.key[slot], kEmpty, lab);
+                    if (old == kEmpty || old == lab) {
+                        inserted = old == kEmpty;
+                        break;
+                    }
+                }
+                slot = (slot + 1) & (kHash - 1);
+            }
+            T.owner[slot] = lane;
+        }
+        nent += __popcll(__ballot(inserted));
+        __builtin_amdgcn_wave_barrier();
+        const bool lose = tail && T.owner[slot] != lane;
+        if (__ballot(lose) == 0ull) {
+            if (tail) {
+                T.cnt[slot] += c;
+                T.sx[slot] += ax;
+                T.sy[slot] += ay;
+            }
+        } else {  // two runs of one label in this chunk: fold them in lane order
+            unsigned long long m = __ballot(tail);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (lane == l) {
+                    T.cnt[slot] += c;
+                    T.sx[slot] += ax;
+                    T.sy[slot] += ay;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (DEBUG) {  // every beam learns the slot of its run (from the run's tail)
+            const unsigned long long tm = __ballot(tail);
+            const int mytail = lane + (int)__builtin_ctzll((tm >> lane) | (1ull << 63));
+            const int sl = __shfl(slot, mytail & (kWave - 1), kWave);
+            if (valid) bloc[j] = sl;
+        }
+        if (nent > kGroupCap) overflow = true;
         __builtin_amdgcn_wave_barrier();
     }
+    // compact the used slots into the staging area, slot order
+    int written = 0;
     bool isnew = false;
-    for (int q = lane; q < nent; q += kWave) {
-        st_label[j0 + q] = s.tlab[q];
-        st_k[j0 + q] = s.tk[q];
-        st_sx[j0 + q] = s.tsx[q];
-        st_sy[j0 + q] = s.tsy[q];
-        isnew |= s.tlab[q] == -1;
+    for (int s0 = 0; s0 < kHash; s0 += kWave) {
+        const int s = s0 + lane;
+        const int k = T.key[s];
+        const bool occ = k != kEmpty;
+        const unsigned long long mask = __ballot(occ);
+        if (occ) {
+            const int q = written + prefix_count(mask, lane);
+            st_label[j0 + q] = k;
+            st_k[j0 + q] = T.cnt[s];
+            st_sbx[j0 + q] = T.sx[s];
+            st_sby[j0 + q] = T.sy[s];
+            isnew |= k == -1;
+            if (DEBUG) T.owner[s] = q;
+        }
+        written += __popcll(mask);
     }
     const unsigned long long anynew = __ballot(isnew);
     if (lane == 0) {
-        nent_out[tl] = nent;
+        nent_out[tl] = written;
         isnew_out[tl] = anynew != 0ull;
         if (overflow) flags[0] = 1;
     }
+    if (DEBUG) {  // beam -> entry index within the pose
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int j = j0 + lane; j < j1; j += kWave) bloc[j] = T.owner[bloc[j]];
+    }
 }
 
-// Entries -> pose-major compact arrays; the gated-out group of a pose gets the fresh id
+// Entries -> pose-major compact arrays.  The gated-out group of a pose gets the fresh id
 // lact0 + (number of earlier poses that created a landmark) (phase B).
-__global__ __launch_bounds__(kBlock) void k_compact(int nloc, const int* __restrict__ boff,
+// Per entry: count, mean body point (energy item), sum of world points k p + R sum b
+// (running-mean term).  Per pose: the pooled within-entry scatter C = sum_j b b^T - sum_e k
+// bbar bbar^T of the energy's scatter term.
+__global__ __launch_bounds__(kBlock) void k_compact(const double* __restrict__ x, const double* __restrict__ x0,
+                                                    int t_begin, int nloc, const int* __restrict__ boff,
                                                     const int* __restrict__ ent_off, const int* __restrict__ new_rank,
                                                     int lact0, const int* __restrict__ st_label,
-                                                    const int* __restrict__ st_k, const double* __restrict__ st_sx,
-                                                    const double* __restrict__ st_sy, unsigned* __restrict__ e_key,
-                                                    int* __restrict__ e_val, int* __restrict__ e_k,
-                                                    double* __restrict__ e_sx, double* __restrict__ e_sy) {
+                                                    const int* __restrict__ st_k, const double* __restrict__ st_sbx,
+                                                    const double* __restrict__ st_sby, const double* __restrict__ pose_s2,
+                                                    unsigned* __restrict__ e_key, int* __restrict__ e_val,
+                                                    int* __restrict__ e_k, double* __restrict__ e_bx,
+                                                    double* __restrict__ e_by, double* __restrict__ e_wx,
+                                                    double* __restrict__ e_wy, double* __restrict__ e_wrx,
+                                                    double* __restrict__ e_wry, double* __restrict__ pose_c) {
     const int lane = lane_id();
     const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (tl >= nloc) return;
     const int j0 = boff[tl], e0 = ent_off[tl], n = ent_off[tl + 1] - e0;
+    double px, py, th;
+    pose_of(x, x0, t_begin + tl, px, py, th);
+    const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
+    double mxx = 0.0, mxy = 0.0, myy = 0.0;
     for (int q = lane; q < n; q += kWave) {
         int lab = st_label[j0 + q];
         if (lab < 0) lab = lact0 + new_rank[tl];
+        const int k = st_k[j0 + q];
+        const double kd = (double)k, sbx = st_sbx[j0 + q], sby = st_sby[j0 + q];
         e_key[e0 + q] = (unsigned)lab;
         e_val[e0 + q] = e0 + q;
-        e_k[e0 + q] = st_k[j0 + q];
-        e_sx[e0 + q] = st_sx[j0 + q];
-        e_sy[e0 + q] = st_sy[j0 + q];
+        e_k[e0 + q] = k;
+        e_bx[e0 + q] = sbx / kd;
+        e_by[e0 + q] = sby / kd;
+        const double rx = ct * sbx - st * sby, ry = st * sbx + ct * sby;  // R sum b
+        e_wx[e0 + q] = kd * px + rx;
+        e_wy[e0 + q] = kd * py + ry;
+        e_wrx[e0 + q] = rx / kd;
+        e_wry[e0 + q] = ry / kd;
+        mxx += sbx * sbx / kd;
+        mxy += sbx * sby / kd;
+        myy += sby * sby / kd;
+    }
+    mxx = wave_sum(mxx);
+    mxy = wave_sum(mxy);
+    myy = wave_sum(myy);
+    if (lane == 0) {
+        pose_c[3 * (size_t)tl] = pose_s2[3 * (size_t)tl] - mxx;
+        pose_c[3 * (size_t)tl + 1] = pose_s2[3 * (size_t)tl + 1] - mxy;
+        pose_c[3 * (size_t)tl + 2] = pose_s2[3 * (size_t)tl + 2] - myy;
     }
 }
 
@@ -427,25 +615,78 @@ __global__ __launch_bounds__(kBlock) void k_lm_bounds(const unsigned* __restrict
     lm_off[i] = lo;
 }
 
-// Local sufficient statistics of every label: (sum x, sum y, n) over this rank's poses in
-// time order.  stats layout: [sx(L) | sy(L) | n(L) | header(8)].
-__global__ __launch_bounds__(kBlock) void k_lm_local(int nlab, int L, const int* __restrict__ lm_off,
-                                                     const int* __restrict__ sval, const int* __restrict__ e_k,
-                                                     const double* __restrict__ e_sx, const double* __restrict__ e_sy,
-                                                     double* __restrict__ stats) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+// ---------------------------------------------------------------------------------------
+// Phase B/D, the per-landmark gather: one wave per label walks the label's entries in time
+// order (they are contiguous in the label-sorted entry ids) and forms the inclusive prefix
+// of the sufficient statistics (n, sum x, sum y), seeded with the lower ranks' totals.
+//   TOTALS: only the landmark's local totals are wanted (sharded run, before the exchange):
+//           stats layout [sx(L) | sy(L) | n(L) | header(8)];
+//   else:   target of every entry = running mean through that pose inclusive (SURVEY
+//           Appendix A.3/A.6 phase B), and (single rank) the raw map y = S/n, cant_obs_i = n.
+// ---------------------------------------------------------------------------------------
+template <bool TOTALS>
+__global__ __launch_bounds__(kBlock) void k_lm_scan(int nlab, int L, const int* __restrict__ lm_off,
+                                                    const int* __restrict__ sval, const int* __restrict__ e_k,
+                                                    const double* __restrict__ e_wx, const double* __restrict__ e_wy,
+                                                    const double* __restrict__ off_sx, const double* __restrict__ off_sy,
+                                                    const double* __restrict__ off_n, double* __restrict__ tgt_x,
+                                                    double* __restrict__ tgt_y, double* __restrict__ stats,
+                                                    double* __restrict__ y_raw, double* __restrict__ cnt_raw) {
+    const int lane = lane_id();
+    const int i = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (i >= L) return;
-    double sx = 0.0, sy = 0.0, n = 0.0;
-    if (i < nlab)
-        for (int p = lm_off[i]; p < lm_off[i + 1]; ++p) {
-            const int e = sval[p];
-            sx += e_sx[e];
-            sy += e_sy[e];
-            n += (double)e_k[e];
+    double cx = 0.0, cy = 0.0, cn = 0.0;
+    if (i < nlab) {
+        if (!TOTALS && off_n) {
+            cx = off_sx[i];
+            cy = off_sy[i];
+            cn = off_n[i];
         }
-    stats[i] = sx;
-    stats[L + i] = sy;
-    stats[2 * L + i] = n;
+        const int p0 = lm_off[i], p1 = lm_off[i + 1];
+        for (int base = p0; base < p1; base += kWave) {
+            const int p = base + lane;
+            const bool valid = p < p1;
+            const int last = min(kWave, p1 - base) - 1;
+            int e = 0;
+            double vx = 0.0, vy = 0.0, vn = 0.0;
+            if (valid) {
+                e = sval[p];
+                vx = e_wx[e];
+                vy = e_wy[e];
+                vn = (double)e_k[e];
+            }
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const double ux = __shfl_up(vx, d, kWave), uy = __shfl_up(vy, d, kWave), un = __shfl_up(vn, d, kWave);
+                if (lane >= d) {
+                    vx += ux;
+                    vy += uy;
+                    vn += un;
+                }
+            }
+            vx += cx;
+            vy += cy;
+            vn += cn;
+            if (!TOTALS && valid) {
+                tgt_x[e] = vx / vn;
+                tgt_y[e] = vy / vn;
+            }
+            cx = __shfl(vx, last, kWave);
+            cy = __shfl(vy, last, kWave);
+            cn = __shfl(vn, last, kWave);
+        }
+    }
+    if (lane == 0) {
+        if (TOTALS) {
+            stats[i] = cx;
+            stats[L + i] = cy;
+            stats[2 * L + i] = cn;
+        } else if (y_raw) {
+            cnt_raw[i] = cn;
+            y_raw[i] = cn > 0.0 ? cx / cn : 0.0;
+            y_raw[L + i] = cn > 0.0 ? cy / cn : 0.0;
+        }
+    }
 }
 
 // After the all-gather of the per-rank statistics: for existing landmarks (i < lact0) the
@@ -477,8 +718,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_prefix(const double* __restric
         y_raw[L + i] = n > 0.0 ? sy / n : 0.0;
     } else {
         off_sx[i] = off_sy[i] = off_n[i] = 0.0;
-        // which rank's new landmark lands in column i?
-        int q = i - lact0;
+        int q = i - lact0;  // which rank's new landmark lands in column i?
         double sx = 0.0, sy = 0.0, n = 0.0;
         for (int r = 0; r < world; ++r) {
             const double* s = stats_all + (size_t)r * stride;
@@ -497,29 +737,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_prefix(const double* __restric
     }
 }
 
-// Running-mean target of every (pose, landmark) entry: the mean of all observations of the
-// landmark through that pose inclusive (SURVEY Appendix A.3/A.6 phase B), as prefix sums of
-// the sufficient statistics in time order, seeded with the lower ranks' totals.
-__global__ __launch_bounds__(kBlock) void k_lm_chain(int nlab, const int* __restrict__ lm_off,
-                                                     const int* __restrict__ sval, const int* __restrict__ e_k,
-                                                     const double* __restrict__ e_sx, const double* __restrict__ e_sy,
-                                                     const double* __restrict__ off_sx, const double* __restrict__ off_sy,
-                                                     const double* __restrict__ off_n, double* __restrict__ tgt_x,
-                                                     double* __restrict__ tgt_y) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nlab) return;
-    double sx = off_sx[i], sy = off_sy[i], n = off_n[i];
-    for (int p = lm_off[i]; p < lm_off[i + 1]; ++p) {
-        const int e = sval[p];
-        sx += e_sx[e];
-        sy += e_sy[e];
-        n += (double)e_k[e];
-        tgt_x[e] = sx / n;
-        tgt_y[e] = sy / n;
-    }
-}
-
-// Target per kept beam: y[:, c] of scripts/ICM_ROS.py:152.
+// Target per kept beam: y[:, c] of scripts/ICM_ROS.py:152 (parity tests, per-beam energy).
 __global__ __launch_bounds__(kBlock) void k_beam_targets(int nloc, const int* __restrict__ boff,
                                                          const int* __restrict__ ent_off, const int* __restrict__ bloc,
                                                          const double* __restrict__ tgt_x, const double* __restrict__ tgt_y,
@@ -544,8 +762,11 @@ struct SolveArgs {
     const double* odo;    // (3,T)
     const double* u;      // (2,T)
     int T, t_begin, nloc;
+    int per_beam;         // 1: energy summed beam by beam (needs btx/bty); 0: entry form
     const int* boff;
     const double *bx, *by, *btx, *bty;
+    const int *ent_off, *e_k;
+    const double *e_bx, *e_by, *tgt_x, *tgt_y, *pose_c, *pose_m;
     double dt, R0, R1, R2, Q0, Q1, cte;
     double* diag;         // optional (T,3): f, nit, nfev per pose
 };
@@ -555,6 +776,7 @@ __device__ __forceinline__ void load3(const double* __restrict__ a, int T, int t
 }
 
 // Solve pose tg (global index); `prev` = x[:,tg-1] as it stands now.
+template <bool PER_BEAM>
 __device__ __forceinline__ void solve_pose(const SolveArgs& a, int tg, const double prev[3], double res[3], int lane) {
     const int tl = tg - a.t_begin;
     const int j0 = a.boff[tl], n = a.boff[tl + 1] - j0;
@@ -581,7 +803,6 @@ __device__ __forceinline__ void solve_pose(const SolveArgs& a, int tg, const dou
         load3(a.odo, a.T, tg + 1, op);
     }
     make_ctx(c, !last, prev, xp, ua, ut, oa, ot, op);
-    Items it{a.bx + j0, a.by + j0, a.btx + j0, a.bty + j0, nullptr, 0.0, n};
     double sx, sy, st;
     if (!last) {  // minimizar_xn start (scripts/ICM_ROS.py:217)
         sx = (prev[0] + xp[0]) / 2.0; sy = (prev[1] + xp[1]) / 2.0; st = (prev[2] + xp[2]) / 2.0;
@@ -589,7 +810,25 @@ __device__ __forceinline__ void solve_pose(const SolveArgs& a, int tg, const dou
         sx = c.gax; sy = c.gay; st = c.gat;
     }
     double out[6];
-    nelder_mead3([&](double px, double py, double th) { return pose_energy(c, it, px, py, th, lane); }, sx, sy, st, out);
+    if (PER_BEAM) {
+        Items it{a.bx + j0, a.by + j0, a.btx + j0, a.bty + j0, nullptr, 0.0, 0.0, 0.0, n};
+        nelder_mead3([&](double px, double py, double th) { return pose_energy(c, it, px, py, th, lane); }, sx, sy, st, out);
+    } else {
+        const int e0 = a.ent_off[tl], ne = a.ent_off[tl + 1] - e0;
+        Items it{a.e_bx + e0, a.e_by + e0, a.tgt_x + e0, a.tgt_y + e0, a.e_k + e0,
+                 a.pose_c[3 * (size_t)tl], a.pose_c[3 * (size_t)tl + 1], a.pose_c[3 * (size_t)tl + 2], ne};
+        // the usual case: at most one entry per lane, held in registers for the whole solve
+        RegItem r{0.0, 0.0, 0.0, 0.0, 0.0};
+        const bool inreg = ne <= kWave;
+        if (inreg && lane < ne) {
+            r.k = (double)it.kw[lane];
+            r.bx = it.bx[lane]; r.by = it.by[lane]; r.tx = it.tx[lane]; r.ty = it.ty[lane];
+        }
+        nelder_mead3([&](double px, double py, double th) {
+            const double hh = inreg ? obs_energy_reg(c, it, r, px, py, th) : obs_energy(c, it, px, py, th, lane);
+            return pose_energy_with(c, hh, px, py, th);
+        }, sx, sy, st, out);
+    }
     res[0] = out[0]; res[1] = out[1]; res[2] = out[2];
     if (a.diag && lane == 0) {
         a.diag[3 * (size_t)tg] = out[3];
@@ -598,8 +837,124 @@ __device__ __forceinline__ void solve_pose(const SolveArgs& a, int tg, const dou
     }
 }
 
+// Moments of the moment-form energy (icm_device.hpp, PoseMoments): one wave per pose reduces
+// its entries; stored [17][nloc] so that the lane-per-pose solver reads them coalesced.
+__global__ __launch_bounds__(kBlock) void k_pose_moments(const double* __restrict__ x, const double* __restrict__ x0,
+                                                         int t_begin, int nloc, const int* __restrict__ ent_off,
+                                                         const int* __restrict__ e_k, const double* __restrict__ e_wrx,
+                                                         const double* __restrict__ e_wry, const double* __restrict__ tgt_x,
+                                                         const double* __restrict__ tgt_y, const double* __restrict__ pose_c,
+                                                         double* __restrict__ pose_m) {
+    const int lane = lane_id();
+    const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (tl >= nloc) return;
+    double px, py, th;
+    pose_of(x, x0, t_begin + tl, px, py, th);
+    double m[kMomentCount];
+#pragma unroll
+    for (int q = 0; q < kMomentCount; ++q) m[q] = 0.0;
+    for (int e = ent_off[tl] + lane; e < ent_off[tl + 1]; e += kWave) {
+        const double k = (double)e_k[e], wx = e_wrx[e], wy = e_wry[e];
+        const double rx = (px + wx) - tgt_x[e], ry = (py + wy) - tgt_y[e];
+        m[0] += k; m[1] += k * wx; m[2] += k * wy; m[3] += k * rx; m[4] += k * ry;
+        m[5] += k * wx * wx; m[6] += k * wy * wy; m[7] += k * wx * wy;
+        m[8] += k * wx * rx; m[9] += k * wy * rx; m[10] += k * wx * ry; m[11] += k * wy * ry;
+        m[12] += k * rx * rx; m[13] += k * ry * ry;
+    }
+#pragma unroll
+    for (int q = 0; q < kMomentCount; ++q) m[q] = wave_sum(m[q]);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kMomentCount; ++q) pose_m[(size_t)q * nloc + tl] = m[q];
+        pose_m[(size_t)14 * nloc + tl] = pose_c[3 * (size_t)tl];
+        pose_m[(size_t)15 * nloc + tl] = pose_c[3 * (size_t)tl + 1];
+        pose_m[(size_t)16 * nloc + tl] = pose_c[3 * (size_t)tl + 2];
+    }
+}
+
+// One LANE solves pose tg with the moment-form energy.  `prev` = x[:,tg-1] as it stands now.
+__device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, const double prev[3], double res[3]) {
+    const int tl = tg - a.t_begin;
+    const int n = a.boff[tl + 1] - a.boff[tl];
+    const bool last = tg + 1 >= a.T;
+    if (n == 0) {  // no beams (scripts/ICM_ROS.py:143-147)
+        const double* nx = a.x + 3 * (size_t)(tg + 1);
+        const double p0 = tg == 1 ? a.x0[0] : prev[0], p1 = tg == 1 ? a.x0[1] : prev[1], p2 = tg == 1 ? a.x0[2] : prev[2];
+        res[0] = (p0 + nx[0]) / 2.0;
+        res[1] = (p1 + nx[1]) / 2.0;
+        res[2] = (p2 + nx[2]) / 2.0;
+        return;
+    }
+    SolveCtx c;
+    c.dt = a.dt; c.R0 = a.R0; c.R1 = a.R1; c.R2 = a.R2; c.Q0 = a.Q0; c.Q1 = a.Q1; c.cte = a.cte;
+    double xp[3] = {0, 0, 0}, ua[2], ut[2] = {0, 0}, oa[3], ot[3], op[3] = {0, 0, 0};
+    ua[0] = a.u[tg - 1]; ua[1] = a.u[(size_t)a.T + tg - 1];
+    load3(a.odo, a.T, tg - 1, oa);
+    load3(a.odo, a.T, tg, ot);
+    if (!last) {
+        xp[0] = a.x[3 * (size_t)(tg + 1)]; xp[1] = a.x[3 * (size_t)(tg + 1) + 1]; xp[2] = a.x[3 * (size_t)(tg + 1) + 2];
+        ut[0] = a.u[tg]; ut[1] = a.u[(size_t)a.T + tg];
+        load3(a.odo, a.T, tg + 1, op);
+    }
+    make_ctx(c, !last, prev, xp, ua, ut, oa, ot, op);
+    PoseMoments m;
+    const double* pm = a.pose_m + tl;
+    const size_t st_ = (size_t)a.nloc;
+    m.S = pm[0]; m.Swx = pm[st_]; m.Swy = pm[2 * st_]; m.Srx = pm[3 * st_]; m.Sry = pm[4 * st_];
+    m.Swxx = pm[5 * st_]; m.Swyy = pm[6 * st_]; m.Swxy = pm[7 * st_]; m.Swxrx = pm[8 * st_]; m.Swyrx = pm[9 * st_];
+    m.Swxry = pm[10 * st_]; m.Swyry = pm[11 * st_]; m.Srxx = pm[12 * st_]; m.Sryy = pm[13 * st_];
+    m.cxx = pm[14 * st_]; m.cxy = pm[15 * st_]; m.cyy = pm[16 * st_];
+    // expansion point = this pose's previous-sweep value (still in x: nobody else writes it)
+    m.pox = a.x[3 * (size_t)tg]; m.poy = a.x[3 * (size_t)tg + 1];
+    sincos(a.x[3 * (size_t)tg + 2], &m.so, &m.co);
+    double sx, sy, st;
+    if (!last) {
+        sx = (prev[0] + xp[0]) / 2.0; sy = (prev[1] + xp[1]) / 2.0; st = (prev[2] + xp[2]) / 2.0;
+    } else {
+        sx = c.gax; sy = c.gay; st = c.gat;
+    }
+    double out[6];
+    nelder_mead3([&](double px, double py, double th) { return pose_energy_moments(c, m, px, py, th); }, sx, sy, st, out);
+    res[0] = out[0]; res[1] = out[1]; res[2] = out[2];
+    if (a.diag) {
+        a.diag[3 * (size_t)tg] = out[3];
+        a.diag[3 * (size_t)tg + 1] = out[4];
+        a.diag[3 * (size_t)tg + 2] = out[5];
+    }
+}
+
+// Red-black half sweep, moment form: one LANE per pose of the colour (64 poses per wave).
+__global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colour) {
+    const int w = blockIdx.x * kBlock + threadIdx.x;
+    int first = a.t_begin > 1 ? a.t_begin : 1;
+    if ((first & 1) != colour) ++first;
+    const int tg = first + 2 * w;
+    if (tg >= a.t_begin + a.nloc) return;
+    double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
+    double res[3];
+    solve_pose_moments(a, tg, prev, res);
+    a.x[3 * (size_t)tg] = res[0];
+    a.x[3 * (size_t)tg + 1] = res[1];
+    a.x[3 * (size_t)tg + 2] = res[2];
+}
+
+// Reference order, moment form: a single lane walks the chain t = 1..T-1.
+__global__ __launch_bounds__(kWave) void k_solve_m_sequential(SolveArgs a) {
+    if (threadIdx.x != 0) return;
+    double prev[3] = {a.x[0], a.x[1], a.x[2]};
+    for (int tg = 1; tg < a.T; ++tg) {
+        double res[3];
+        solve_pose_moments(a, tg, prev, res);
+        a.x[3 * (size_t)tg] = res[0];
+        a.x[3 * (size_t)tg + 1] = res[1];
+        a.x[3 * (size_t)tg + 2] = res[2];
+        prev[0] = res[0]; prev[1] = res[1]; prev[2] = res[2];
+    }
+}
+
 // Red-black half sweep: all poses of one parity (colour = tg & 1) of this shard, one wave
 // each.  Neighbours have the other parity, so nothing read here is written by this launch.
+template <bool PER_BEAM>
 __global__ __launch_bounds__(kBlock) void k_solve_colour(SolveArgs a, int colour) {
     const int lane = lane_id();
     const int w = blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -609,7 +964,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_colour(SolveArgs a, int colour
     if (tg >= a.t_begin + a.nloc) return;
     double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
     double res[3];
-    solve_pose(a, tg, prev, res, lane);
+    solve_pose<PER_BEAM>(a, tg, prev, res, lane);
     if (lane == 0) {
         a.x[3 * (size_t)tg] = res[0];
         a.x[3 * (size_t)tg + 1] = res[1];
@@ -619,12 +974,13 @@ __global__ __launch_bounds__(kBlock) void k_solve_colour(SolveArgs a, int colour
 
 // Reference order: one wave walks the chain t = 1..T-1, each solve conditioned on the pose
 // it has just written (Gauss-Seidel, scripts/ICM_ROS.py:141-158).
+template <bool PER_BEAM>
 __global__ __launch_bounds__(kWave) void k_solve_sequential(SolveArgs a) {
     const int lane = lane_id();
     double prev[3] = {a.x[0], a.x[1], a.x[2]};
     for (int tg = 1; tg < a.T; ++tg) {
         double res[3];
-        solve_pose(a, tg, prev, res, lane);
+        solve_pose<PER_BEAM>(a, tg, prev, res, lane);
         if (lane == 0) {
             a.x[3 * (size_t)tg] = res[0];
             a.x[3 * (size_t)tg + 1] = res[1];
@@ -648,7 +1004,7 @@ __global__ __launch_bounds__(kWave) void k_solve_one(OneArgs a) {
     c.dt = a.dt; c.R0 = a.R0; c.R1 = a.R1; c.R2 = a.R2; c.Q0 = a.Q0; c.Q1 = a.Q1; c.cte = a.cte;
     const double* p = a.p;
     make_ctx(c, a.two_sided, p + 3, p + 6, p + 9, p + 11, p + 13, p + 16, p + 19);
-    Items it{a.bx, a.by, a.tx, a.ty, nullptr, 0.0, a.n};
+    Items it{a.bx, a.by, a.tx, a.ty, nullptr, 0.0, 0.0, 0.0, a.n};
     double out[6] = {0, 0, 0, 0, 0, 0};
     if (a.energy_only == 2) {
         out[3] = obs_energy(c, it, p[0], p[1], p[2], lane);
@@ -665,12 +1021,6 @@ __global__ __launch_bounds__(kWave) void k_solve_one(OneArgs a) {
     }
     if (lane == 0)
         for (int i = 0; i < 6; ++i) a.out[i] = out[i];
-}
-
-// (3,T) <-> (T,3) pose layout change between the reference's host layout and HBM.
-__global__ void k_fill_i32(int* p, int v, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
 }
 
 }  // namespace icm

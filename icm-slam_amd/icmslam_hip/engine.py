@@ -246,6 +246,15 @@ class SweepEngine:
         """fun_xn (two_sided) / fun_x at pose x, evaluated on the GPU."""
         return self._one(True, two_sided, x, x_ant, x_pos, u, odo, bx, by, tx, ty)
 
+    def set_debug(self, on=True):
+        """Keep per-beam labels / targets of the next sweeps (for `association()`)."""
+        self._chk(self.lib.icm_set_debug(self.h, int(bool(on))))
+
+    def set_energy_form(self, form):
+        """0 / 'moments' (default), 1 / 'beam' (literal per-beam sum), 2 / 'entry'."""
+        form = {"moments": 0, "beam": 1, "entry": 2}.get(form, form)
+        self._chk(self.lib.icm_set_energy_form(self.h, int(form)))
+
     def set_brute_force(self, on):
         self._chk(self.lib.icm_set_brute_force(self.h, int(bool(on))))
 

@@ -155,6 +155,19 @@ int icm_filtrar(const icm_config *cfg, const double *y, const double *counts, in
  * mapa_viejo, table tiled through LDS) instead of the grid search.  Same results. */
 int icm_set_brute_force(icm_handle *h, int on);
 
+/* Keep the per-beam outputs of a sweep (label and running-mean target of every kept beam)
+ * for icm_get_association; off by default (they cost 28 B of HBM traffic per kept beam). */
+int icm_set_debug(icm_handle *h, int on);
+/* Form in which the pose solves evaluate the observation energy h(x) of
+ * scripts/ICM_ROS.py:171-200 -- the same function in three algebraically identical forms:
+ *   0 (default) moment form: quadratic form in (dp, cos d - 1, sin d) about the pose's
+ *               previous value, 14 sums per pose; one LANE solves a pose
+ *   1           one term per kept beam, literally the reference's sum; one wave per pose
+ *   2           one term per (pose, landmark) entry: k |p + R bbar - y|^2_Q + scatter; one
+ *               wave per pose
+ * Forms 1 and 2 exist to cross-check form 0. */
+int icm_set_energy_form(icm_handle *h, int form);
+
 /* ---- instrumentation -------------------------------------------------------------------- */
 /* When enabled, every kernel launch of a sweep is bracketed by HIP events on the handle's
  * stream; icm_kernel_time() returns accumulated ms and launch count per kernel name. */

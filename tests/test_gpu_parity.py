@@ -74,12 +74,19 @@ def _pose_report(x, xref, what):
     return d, loose
 
 
-def test_sweep1_sequential_matches_reference(engine, init_state):
+@pytest.mark.parametrize("form", ["moments", "beam", "entry"])
+def test_sweep1_sequential_matches_reference(engine, init_state, form):
     x_init, map_init, lact = init_state
     _, odo, _ = dataset()
     g = gold("sweep01.npz")
     x = x_init.copy()
-    mo, co, K = engine.sweep(map_init, x, odo[:, 0], lact, "sequential")
+    engine.set_debug(True)
+    engine.set_energy_form(form)
+    try:
+        mo, co, K = engine.sweep(map_init, x, odo[:, 0], lact, "sequential")
+    finally:
+        engine.set_debug(False)
+        engine.set_energy_form("moments")
     # phase A: labels of every kept beam and the running-mean targets of every solved pose
     pp = gold("sweep1_perpose.npz")
     lab, tx, ty = engine.association()
@@ -140,15 +147,17 @@ def test_brute_force_association_equals_grid(engine, init_state):
     x_init, map_init, lact = init_state
     _, odo, _ = dataset()
     x = x_init.copy()
-    engine.sweep(map_init, x, odo[:, 0], lact, "sequential")
-    lab_grid = engine.association()[0].copy()
-    engine.set_brute_force(True)
+    engine.set_debug(True)
     try:
+        engine.sweep(map_init, x, odo[:, 0], lact, "sequential")
+        lab_grid = engine.association()[0].copy()
+        engine.set_brute_force(True)
         x2 = x_init.copy()
         engine.sweep(map_init, x2, odo[:, 0], lact, "sequential")
         lab_brute = engine.association()[0].copy()
     finally:
         engine.set_brute_force(False)
+        engine.set_debug(False)
     assert np.array_equal(lab_grid, lab_brute)
     assert np.array_equal(x, x2)
 
