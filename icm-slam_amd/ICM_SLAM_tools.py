@@ -104,6 +104,25 @@ class Mapa:
             "ICM_ROS.iterations_process_offline instead of updating the map scan by scan")
 
 
+def filtrar_z(z, config):
+    """Scan pre-filter (reference scripts/ICM_SLAM_tools.py:22-58): 3-tap median, max-range cut,
+    isolated-beam rejection; rows [d, ang, d cos ang, d sin ang].  Runs the HIP kernel the
+    sweep uses (`k_prefilter`)."""
+    return _engine.prefilter_scans(config, np.asarray(z, dtype=np.float64).reshape(-1))[0]
+
+
+def tras_rot_z(x, z):
+    """Body -> world transform of the kept beams, in place on columns 2:4 like the reference
+    (scripts/ICM_SLAM_tools.py:465-480).  Inside a sweep this is fused into `k_assoc_group`."""
+    x = np.asarray(x, dtype=np.float64).reshape(3)
+    ct = np.cos(x[2] - np.pi / 2.0)
+    st = np.sin(x[2] - np.pi / 2.0)
+    bx, by = z[:, 2].copy(), z[:, 3].copy()
+    z[:, 2] = (bx * ct - by * st) + x[0]
+    z[:, 3] = (bx * st + by * ct) + x[1]
+    return z
+
+
 def entrepi(angulo):
     """Equivalent angle in (-pi, pi] (reference scripts/ICM_SLAM_tools.py:455-463)."""
     angulo = np.mod(angulo, 2 * np.pi)

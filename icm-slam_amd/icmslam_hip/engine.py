@@ -59,6 +59,38 @@ def filtrar_map(config, y, counts, lact):
     return yo, co, int(lo.value)
 
 
+_PREFILTER_ENGINES = {}
+
+
+def prefilter_scans(config, scans, device=0):
+    """filtrar_z for the columns of `scans` (B,n) on the GPU (reference
+    scripts/ICM_SLAM_tools.py:22-58).  Returns a list of (n_t,4) arrays [d, ang, bx, by];
+    an empty (0,) array where the reference returns `np.array([])`."""
+    scans = np.asarray(scans, dtype=np.float64)
+    if scans.ndim == 1:
+        scans = scans[:, None]
+    B, n = scans.shape
+    key = (id(config), device)
+    eng = _PREFILTER_ENGINES.get(key)
+    if eng is None:
+        eng = _PREFILTER_ENGINES[key] = SweepEngine(config, device)
+    pad = max(2 - n, 0)
+    if pad:
+        scans = np.concatenate((scans, np.repeat(scans[:, -1:], pad, axis=1)), axis=1)
+    T = scans.shape[1]
+    eng.upload(scans, np.zeros((3, T)), np.zeros((2, T)))
+    off, bk, d, bx, by = eng.kept_beams()
+    _, _, ang = bearing_tables(B, getattr(config, "angle_increment", None))
+    out = []
+    for t in range(n):
+        sl = slice(off[t], off[t + 1])
+        if off[t + 1] == off[t]:
+            out.append(np.array([]))
+        else:
+            out.append(np.stack((d[sl], ang[bk[sl]], bx[sl], by[sl]), axis=1))
+    return out
+
+
 def _raise(rc, msg):
     if rc == _lib.ICM_ERR_INDEX:
         raise IndexError(msg)

@@ -1,0 +1,101 @@
+"""The reference's class surface on the GPU: a driver written like scripts/example.py /
+scripts/ICM_ROS.py:298-311 runs unchanged against icm-slam_amd/ and reproduces the reference's
+own results (BASELINE.json configs[0]/[1]: data_IJAC2018, default config, N = 2)."""
+import os
+from copy import deepcopy as copy
+
+import numpy as np
+import pytest
+
+from util import GOLD, gold
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def icm():
+    from ICM_ROS import ICM_ROS
+    from ICM_SLAM_tools import ConfigICM
+    config = ConfigICM("config_default.yaml")          # unloadable by the reference itself
+    m = ICM_ROS(config)
+    m.load_data(os.path.join(GOLD, "data_IJAC2018.npz"))
+    init = gold("init_pass.npz")
+    m.set_initial_state(init["x_init"], init["map_init"], init["cant_obs_i"])
+    return m
+
+
+def test_driver_loop_reproduces_reference(icm):
+    mapa_viejo = copy(icm.mapa_viejo)
+    x = copy(icm.positions)
+    assert icm.config.N == 2
+    for it in range(icm.config.N):
+        x_id = id(x)
+        mapa_refinado, x = icm.iterations_process_offline(mapa_viejo, x)
+        assert id(x) == x_id                      # updated in place AND returned
+        g = gold("sweep%02d.npz" % (it + 1))
+        assert mapa_refinado.shape == g["mapa"].shape
+        assert np.abs(mapa_refinado - g["mapa"]).max() <= 1e-9
+        assert np.abs(x - g["x"]).max() <= 1e-9
+        assert np.array_equal(icm.mapa_obj.cant_obs_i, g["cant_obs_i"])
+        assert icm.mapa_obj.landmarks_actuales == int(g["landmarks_actuales"])
+        mapa_viejo = copy(mapa_refinado)
+    assert np.array_equal(icm.mapa_viejo, gold("init_pass.npz")["map_init"])   # input map untouched
+
+
+def test_non_contiguous_x_is_updated_in_place(icm):
+    init = gold("init_pass.npz")
+    big = np.zeros((3, 2 * init["x_init"].shape[1]))
+    xv = big[:, ::2]
+    xv[...] = init["x_init"]
+    icm.mapa_obj.landmarks_actuales = init["map_init"].shape[1]
+    m, xr = icm.iterations_process_offline(init["map_init"].copy(), xv)
+    assert xr is xv and np.abs(xv - gold("sweep01.npz")["x"]).max() <= 1e-9
+
+
+def test_model_functions_on_gpu(icm):
+    """h / fun_xn / minimizar_xn with the reference's stashed-state calling convention
+    (scripts/ICM_ROS.py:209-252), against the SURVEY Appendix C known answers."""
+    s = gold("solve_t100.npz")
+    init = gold("init_pass.npz")
+    x = init["x_init"].copy()
+    xo = icm.minimizar_xn(s["beams"][:, 0:2], s["targets"], x, 100)
+    assert np.abs(xo - s["xopt"]).max() <= 1e-9
+    assert abs(icm.fun_xn(s["start"]) - 0.17067461579800194) <= 1e-13
+    assert abs(icm.h(s["start"], s["beams"][:, 0:2]) - 0.169551072251446) <= 1e-13
+    g = icm.g(x[:, 99], icm.u[:, 99])
+    assert g.shape == (3, 1)
+
+
+def test_filtrar_z_helper_matches_reference(icm):
+    from ICM_SLAM_tools import filtrar_z, tras_rot_z
+    fz = gold("filtrar_z.npz")
+    for t in (0, 100, 1832):
+        rows = filtrar_z(icm.mediciones[:, t], icm.config)
+        ref = fz["rows"][fz["offsets"][t]:fz["offsets"][t + 1]]
+        assert rows.shape == ref.shape and np.array_equal(rows, ref)
+    assert filtrar_z(np.full(181, 10.0), icm.config).shape == (0,)   # nothing in range
+    z = filtrar_z(icm.mediciones[:, 0], icm.config)
+    w = tras_rot_z(np.array([1.0, 2.0, 0.3]), z.copy())
+    assert np.allclose(np.hypot(w[:, 2] - 1.0, w[:, 3] - 2.0), z[:, 0])
+
+
+def test_errors_match_reference_types(icm):
+    from ICM_ROS import ICM_ROS
+    from ICM_SLAM_tools import ConfigICM
+    init = gold("init_pass.npz")
+    # label capacity exceeded -> IndexError (scripts/ICM_SLAM_tools.py:191)
+    cfg = ConfigICM(D=dict(N=1, deltat=0.1, L=12, Q=[1, 1], R=[1, 1, 1], cte_odom=1.0, cota=300.0, dist_thr=1.0,
+                           dist_thr_obs=1.0, rango_laser_max=10.0, radio=0.137))
+    m = ICM_ROS(cfg)
+    m.load_data(os.path.join(GOLD, "data_IJAC2018.npz"))
+    m.set_initial_state(init["x_init"], init["map_init"])
+    with pytest.raises(IndexError):
+        m.iterations_process_offline(init["map_init"].copy(), init["x_init"].copy())
+    # nothing reaches cota -> ValueError
+    cfg2 = ConfigICM(D=dict(N=1, deltat=0.1, L=1000, Q=[1, 1], R=[1, 1, 1], cte_odom=1.0, cota=1e9, dist_thr=1.0,
+                            dist_thr_obs=1.0, rango_laser_max=10.0, radio=0.137))
+    m2 = ICM_ROS(cfg2)
+    m2.load_data(os.path.join(GOLD, "data_IJAC2018.npz"))
+    m2.set_initial_state(init["x_init"], init["map_init"])
+    with pytest.raises(ValueError):
+        m2.iterations_process_offline(init["map_init"].copy(), init["x_init"].copy())

@@ -1,0 +1,114 @@
+"""The CPU oracle against the golden vectors produced by the REAL reference
+(tests/golden/make_golden.py): bit-for-bit, because the oracle restates the reference with
+the same NumPy primitives.  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from oracle import icm_oracle as o
+from util import dataset, gold
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return o.OracleConfig()
+
+
+@pytest.fixture(scope="module")
+def kept(cfg):
+    zz, _, _ = dataset()
+    return o.prefilter_all(zz, cfg)
+
+
+def test_filtrar_z_bitwise(kept):
+    g = gold("filtrar_z.npz")
+    off, rows = g["offsets"], g["rows"]
+    assert len(kept) == len(off) - 1
+    for t, k in enumerate(kept):
+        ref = rows[off[t]:off[t + 1]]
+        got = k if k.ndim == 2 else np.zeros((0, 4))
+        assert got.shape == ref.shape and np.array_equal(got, ref), "scan %d" % t
+
+
+def test_known_answers_appendix_c(kept):
+    """scan 0 keeps beams 61..65,146..148."""
+    k0 = kept[0]
+    assert np.array_equal(np.round(k0[:, 1] * 180 / np.pi).astype(int), [61, 62, 63, 64, 65, 146, 147, 148])
+    assert np.allclose(k0[0], [5.1090001221, 1.0646508437, 2.476892409, 4.4684321905], atol=1e-9)
+
+
+def test_energy_and_nelder_mead_t100(cfg):
+    s = gold("solve_t100.npz")
+    init = gold("init_pass.npz")
+    _, odo, u = dataset()
+    x_init = init["x_init"]
+    t = 100
+    f = lambda v: o.fun_xn(cfg, v, x_init[:, t - 1].reshape(3, 1), x_init[:, t + 1].reshape(3, 1), u, odo, t,  # noqa: E731
+                           s["beams"][:, 0:2], s["targets"])
+    assert o.h(cfg, s["start"], s["beams"][:, 0:2], s["targets"]) == float(s["h_start"]) == 0.169551072251446
+    assert f(s["start"]) == float(s["f_start"])
+    xo, fo, nit, nfev = o.nelder_mead(f, s["start"], full_output=True)
+    assert np.array_equal(xo, s["xopt"]) and fo == float(s["fopt"])
+    assert (nit, nfev) == (int(s["nit"]), int(s["nfev"])) == (26, 52)
+
+
+def test_filtrar_pairs_from_sweep1(cfg):
+    pp = gold("sweep1_perpose.npz")
+    st = o.MapState(cfg, int(pp["filtrar_lact_in"]))
+    st.cant_obs_i[:st.landmarks_actuales] = pp["filtrar_cnt_in"]
+    y = np.zeros((2, cfg.L))
+    y[:, :st.landmarks_actuales] = pp["filtrar_y_in"]
+    out = o.filtrar(st, y)
+    la = int(pp["filtrar_lact_out"])
+    assert st.landmarks_actuales == la
+    assert np.array_equal(out[:, :la], pp["filtrar_y_out"])
+    assert np.array_equal(st.cant_obs_i[:la], pp["filtrar_cnt_out"])
+
+
+@pytest.mark.slow
+def test_two_sweeps_bitwise(cfg, kept):
+    """Two full sweeps of the three-phase oracle == the reference's interleaved loop, bit for
+    bit (poses, map, counters) -- about 30 s."""
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    st = o.MapState(cfg, int(init["landmarks_actuales"]))
+    x = init["x_init"].copy()
+    mv = init["map_init"].copy()
+    for it in (1, 2):
+        mv, x = o.sweep(cfg, st, zz, u, odo, odo[:, 0], mv, x, kept=kept)
+        g = gold("sweep%02d.npz" % it)
+        assert np.array_equal(x, g["x"]) and np.array_equal(mv, g["mapa"])
+        assert np.array_equal(st.cant_obs_i, g["cant_obs_i"]) and st.landmarks_actuales == int(g["landmarks_actuales"])
+
+
+def test_prefix_sweep_three_phase_equals_interleaved(cfg, kept):
+    """SURVEY Appendix A.6 on a 150-pose prefix: phases A+B first, then the solves, is the
+    same computation as the reference's interleaved loop."""
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    T = 150
+    c2 = o.OracleConfig(cota=20.0)
+    res = []
+    for fn in (o.sweep, o.sweep_interleaved):
+        st = o.MapState(c2, int(init["landmarks_actuales"]))
+        x = np.ascontiguousarray(init["x_init"][:, :T]).copy()
+        m, x = fn(c2, st, zz[:, :T], u[:, :T], odo[:, :T], odo[:, 0], init["map_init"].copy(), x, kept=kept[:T])
+        res.append((m, x, st.cant_obs_i.copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][2], res[1][2])
+
+
+def test_redblack_differs_but_stays_close(cfg, kept):
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    T = 120
+    c2 = o.OracleConfig(cota=20.0)
+    out = {}
+    for sch in ("sequential", "redblack"):
+        st = o.MapState(c2, int(init["landmarks_actuales"]))
+        x = np.ascontiguousarray(init["x_init"][:, :T]).copy()
+        m, x = o.sweep(c2, st, zz[:, :T], u[:, :T], odo[:, :T], odo[:, 0], init["map_init"].copy(), x, schedule=sch, kept=kept[:T])
+        out[sch] = (m, x)
+    # the map of a sweep does not depend on the solve order
+    assert np.array_equal(out["sequential"][0], out["redblack"][0])
+    d = np.abs(out["sequential"][1] - out["redblack"][1]).max()
+    assert 0 < d < 0.1
