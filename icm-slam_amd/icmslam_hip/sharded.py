@@ -1,0 +1,107 @@
+"""Pose-sharded ICM sweep: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI) for the two exchanges a sweep needs.
+
+Partition: contiguous pose blocks of `blk = ceil(T / world)` poses; rank r owns poses
+[r*blk, min((r+1)*blk, T)).  Scans live only on their owner; odometry, velocities, the pose
+array and the landmark table are replicated (they are KB..MB).
+
+Per sweep:
+  1. local phase A and per-landmark sufficient statistics (sum x, sum y, n)  [no comm]
+  2. ONE all-gather of the [3L+8] statistics: every rank gets the total (new map) and the
+     exclusive prefix over lower ranks (state of each running mean at its first pose)
+  3. targets, then the odd poses of the shard                                 [no comm]
+  4. all-gather of the pose blocks (neighbours' boundary poses for the even half)
+  5. the even poses, all-gather of the pose blocks
+  6. Mapa.filtrar, replicated (deterministic) on every rank
+
+The payloads are tiny (240 KB of statistics per rank at L = 10k, 2.4 MB of poses), so the
+collectives are latency-bound; xGMI link bandwidth is irrelevant here.
+"""
+import numpy as np
+
+
+def partition(T, world):
+    blk = (T + world - 1) // world
+    return blk, [(min(r * blk, T), min((r + 1) * blk, T)) for r in range(world)]
+
+
+class ShardedSweep:
+    """Drives one rank.  `engine` is a SweepEngine (or anything with the same phase API);
+    `comm` does the collectives: TorchComm (torch.distributed) or NoComm (ranks that share
+    the exchange buffers inside one process)."""
+
+    def __init__(self, engine, rank, world, T, comm=None, buffers=None):
+        import torch
+        self.torch = torch
+        self.eng, self.rank, self.world, self.T = engine, rank, world, T
+        self.blk, self.parts = partition(T, world)
+        self.stride = engine.stats_stride()
+        dev = getattr(engine, "exchange_device", "cuda")
+        if buffers is None:
+            stats = torch.zeros(world * self.stride, dtype=torch.float64, device=dev)
+            poses = torch.zeros(world * self.blk * 3, dtype=torch.float64, device=dev)
+        else:
+            stats, poses = buffers
+        self.stats, self.poses = stats, poses
+        if hasattr(engine, "bind_tensors"):      # test doubles work on the tensors directly
+            engine.bind_tensors(stats, poses, rank, world)
+        else:
+            if dev == "cuda":
+                engine.set_stream(torch.cuda.current_stream().cuda_stream)
+            engine.bind_exchange(stats.data_ptr(), rank, world)
+            engine.bind_pose_buffer(poses.data_ptr())
+        self.comm = comm if comm is not None else TorchComm()
+
+    def set_state(self, mapa_viejo, x, x0, lact=None):
+        self.eng.set_state(mapa_viejo, x, x0, lact)
+
+    def sweep(self, schedule="redblack"):
+        if schedule != "redblack":
+            raise NotImplementedError("only the red-black schedule shards (the reference order is one chain)")
+        e, r = self.eng, self.rank
+        e.sweep_local()
+        self.comm.all_gather(self.stats, r, self.stride)
+        e.sweep_targets()
+        e.sweep_solve("redblack", 1)
+        self.comm.all_gather(self.poses, r, self.blk * 3)
+        e.sweep_solve("redblack", 0)
+        self.comm.all_gather(self.poses, r, self.blk * 3)
+        e.sweep_finish()
+
+    def get_state(self):
+        return self.eng.get_state()
+
+
+class TorchComm:
+    """all_gather_into_tensor on the default process group (NCCL/RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+
+    def all_gather(self, buf, rank, count):
+        mine = buf[rank * count:(rank + 1) * count].clone()
+        self.dist.all_gather_into_tensor(buf, mine, group=self.group)
+
+
+class NoComm:
+    """Ranks living in one process on one GPU and bound to the SAME buffers: every rank's
+    slot is already visible to the others."""
+
+    def all_gather(self, buf, rank, count):
+        pass
+
+
+def run_virtual_ranks(engines, sweeps, schedule="redblack"):
+    """Lock-step execution of several in-process ranks (one GPU, shared buffers): the exact
+    phase order of ShardedSweep.sweep with the collectives replaced by shared memory."""
+    for _ in range(sweeps):
+        for e in engines:
+            e.sweep_local()
+        for e in engines:
+            e.sweep_targets()
+        for colour in (1, 0):
+            for e in engines:
+                e.sweep_solve(schedule, colour)
+        for e in engines:
+            e.sweep_finish()

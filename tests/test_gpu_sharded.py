@@ -1,0 +1,84 @@
+"""The sharded sweep on ONE GPU: several in-process ranks bound to the same exchange buffers
+(the collectives become shared memory), against the unsharded sweep; plus the RCCL
+all-gather path itself with a 1-rank process group."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload():
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip.synthetic import make_workload
+    wl = make_workload(1900, 100, 180)  # lane, turn (some poses see nothing), lane
+    return wl, ConfigICM(D=wl.config)
+
+
+def _single(wl, cfg, sweeps):
+    from icmslam_hip import SweepEngine
+    eng = SweepEngine(cfg)
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    eng.set_state(wl.map_init, wl.x_init, wl.x0)
+    for _ in range(sweeps):
+        eng.sweep_device("redblack")
+    out = eng.get_state()
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_virtual_ranks_match_unsharded(world):
+    import torch
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import NoComm, ShardedSweep, partition, run_virtual_ranks
+    wl, cfg = _workload()
+    sweeps = 3
+    x1, m1, c1, K1 = _single(wl, cfg, sweeps)
+    blk, parts = partition(wl.T, world)
+    engines, runners, buffers = [], [], None
+    for r, (a, b) in enumerate(parts):
+        e = SweepEngine(cfg)
+        e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
+        run = ShardedSweep(e, r, world, wl.T, comm=NoComm(), buffers=buffers)
+        buffers = (run.stats, run.poses)
+        run.set_state(wl.map_init, wl.x_init, wl.x0)
+        engines.append(e)
+        runners.append(run)
+    run_virtual_ranks(engines, sweeps)
+    torch.cuda.synchronize()
+    for e in engines:
+        x, m, c, K = e.get_state()
+        assert K == K1
+        assert np.abs(m[:, :K] - m1[:, :K1]).max() <= 1e-9
+        assert np.array_equal(c, c1)
+        d = np.abs(x - x1).max(axis=0)
+        print("world %d: max|dx| %.3e, poses above 1e-9: %d" % (world, d.max(), int((d > 1e-9).sum())))
+        assert d.max() <= 5e-3 and (d > 1e-9).sum() <= 3
+    for e in engines:
+        e.close()
+
+
+def test_rccl_all_gather_path_one_rank():
+    """ShardedSweep with the real torch.distributed 'nccl' (= RCCL) backend, world size 1:
+    same result as the plain device-resident sweep."""
+    import torch
+    import torch.distributed as dist
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import ShardedSweep
+    wl, cfg = _workload()
+    x1, m1, c1, K1 = _single(wl, cfg, 2)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        e = SweepEngine(cfg)
+        e.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+        run = ShardedSweep(e, 0, 1, wl.T)
+        run.set_state(wl.map_init, wl.x_init, wl.x0)
+        for _ in range(2):
+            run.sweep("redblack")
+        torch.cuda.synchronize()
+        x, m, c, K = run.get_state()
+        e.close()
+    finally:
+        dist.destroy_process_group()
+    assert K == K1 and np.array_equal(x, x1) and np.array_equal(m, m1)
