@@ -2,6 +2,8 @@
 // orchestration.  All device work goes to one HIP stream; the only host round trips per
 // sweep are two small counter reads (entry / new-landmark counts) and the raw-map download
 // for the host-side Mapa.filtrar.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -78,8 +80,10 @@ struct icm_handle {
 
     // association grid
     Grid grid;
-    DevBuf<int> g_cell, g_id;
-    DevBuf<double> g_lx, g_ly, mapx, mapy;
+    DevBuf<int> g_cell;
+    DevBuf<LmRec> g_lm;
+    std::vector<LmRec> h_lm;
+    DevBuf<double> mapx, mapy;
 
     // per-sweep
     DevBuf<int> label, bloc, st_label, st_k, nent, isnew, ent_off, new_rank, e_val, e_k, sval, lm_off, flags, scan_tot;
@@ -102,6 +106,10 @@ struct icm_handle {
     double k_ms[KID_COUNT] = {0};
     int64_t k_n[KID_COUNT] = {0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // raw-map download overlapped with the solves
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_map = nullptr, ev_copied = nullptr;
+    bool map_copy_pending = false;
 };
 
 #define HIPCHK(h, call)                                                                             \
@@ -170,8 +178,11 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
     h->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->ev_map, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_i), 64 * sizeof(int))) != hipSuccess ||
-        (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_d), (size_t)(3 * cfg->L + 16) * sizeof(double))) != hipSuccess) {
+        (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_d), (size_t)(3 * cfg->L + 16 + 64) * sizeof(double))) != hipSuccess) {
         g_create_err = std::string("icm_create: ") + hipGetErrorString(e);
         delete h;
         return ICM_ERR_HIP;
@@ -187,13 +198,14 @@ int icm_destroy(icm_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf<double>* dd[] = {&h->ranges, &h->cosb, &h->sinb, &h->odo, &h->u, &h->bd, &h->bx, &h->by, &h->x_own, &h->x0,
-                            &h->g_lx, &h->g_ly, &h->mapx, &h->mapy, &h->st_sx, &h->st_sy, &h->e_bx, &h->e_by, &h->e_wx, &h->e_wy, &h->e_wrx, &h->e_wry, &h->pose_m, &h->pose_c, &h->pose_s2, &h->tgt_x,
+                            &h->mapx, &h->mapy, &h->st_sx, &h->st_sy, &h->e_bx, &h->e_by, &h->e_wx, &h->e_wy, &h->e_wrx, &h->e_wry, &h->pose_m, &h->pose_c, &h->pose_s2, &h->tgt_x,
                             &h->tgt_y, &h->btx, &h->bty, &h->stats_own, &h->off_sx, &h->off_sy, &h->off_n, &h->y_raw,
                             &h->cnt_raw, &h->diag};
     for (auto* b : dd) b->release();
-    DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->g_id, &h->label, &h->bloc, &h->st_label, &h->st_k,
+    DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->label, &h->bloc, &h->st_label, &h->st_k,
                          &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags, &h->scan_tot};
     for (auto* b : di) b->release();
+    h->g_lm.release();
     h->e_key.release();
     h->skey.release();
     h->sort_tmp.release();
@@ -201,6 +213,9 @@ int icm_destroy(icm_handle* h) {
     if (h->pin_d) (void)hipHostFree(h->pin_d);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_map) (void)hipEventDestroy(h->ev_map);
+    if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ICM_OK;
@@ -285,7 +300,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(8));
     HIPCHK(h, h->stats_own.reserve(3 * L + 8)); HIPCHK(h, h->off_sx.reserve(L)); HIPCHK(h, h->off_sy.reserve(L));
     HIPCHK(h, h->off_n.reserve(L)); HIPCHK(h, h->y_raw.reserve(2 * L)); HIPCHK(h, h->cnt_raw.reserve(L));
-    HIPCHK(h, h->g_lx.reserve(L)); HIPCHK(h, h->g_ly.reserve(L)); HIPCHK(h, h->g_id.reserve(L));
+    HIPCHK(h, h->g_lm.reserve(L));
     HIPCHK(h, h->mapx.reserve(L)); HIPCHK(h, h->mapy.reserve(L));
     HIPCHK(h, h->g_cell.reserve(4 * L + 1024 + 2));
     size_t tmp_bytes = 0;
@@ -325,9 +340,9 @@ static int upload_map(icm_handle* h) {
     HIPCHK(h, h->g_cell.reserve(g.cell_start.size()));
     HIPCHK(h, hipMemcpyAsync(h->g_cell.p, g.cell_start.data(), g.cell_start.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (km > 0) {
-        HIPCHK(h, hipMemcpyAsync(h->g_lx.p, g.lx.data(), (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->g_ly.p, g.ly.data(), (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->g_id.p, g.id.data(), (size_t)km * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        h->h_lm.resize((size_t)km);
+        for (int64_t i = 0; i < km; ++i) h->h_lm[(size_t)i] = LmRec{g.lx[(size_t)i], g.ly[(size_t)i], g.id[(size_t)i], 0, 0, 0};
+        HIPCHK(h, hipMemcpyAsync(h->g_lm.p, h->h_lm.data(), (size_t)km * sizeof(LmRec), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->mapx.p, mx, (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->mapy.p, my, (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
@@ -420,7 +435,7 @@ int icm_sweep_local(icm_handle* h) {
     const int km = (int)std::min(h->K, h->lact);
     const int nbw = nblocks_waves(nloc);
     HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
-    GridView gv{h->grid.gx0, h->grid.gy0, h->grid.inv, h->grid.nx, h->grid.ny, h->g_cell.p, h->g_lx.p, h->g_ly.p, h->g_id.p};
+    GridView gv{h->grid.gx0, h->grid.gy0, h->grid.inv, h->grid.nx, h->grid.ny, h->g_cell.p, h->g_lm.p};
     const bool dbg = h->debug || h->per_beam;
     h->assoc_kept = dbg;
 #define ASSOC_GROUP(PRE, DBG)                                                                                      \
@@ -483,6 +498,18 @@ int icm_sweep_targets(icm_handle* h) {
     if (h->assoc_kept)
         TIMED(h, KID_BEAM_TARGETS, (k_beam_targets<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->bloc.p, h->tgt_x.p, h->tgt_y.p, h->btx.p, h->bty.p)));
     HIPCHK(h, hipGetLastError());
+    // The raw map (and, sharded, the ranks' new-landmark counts) is final here: start its
+    // download on the copy stream so that Mapa.filtrar on the host overlaps the pose solves.
+    HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
+    const size_t Ls = (size_t)L;
+    HIPCHK(h, hipMemcpyAsync(h->pin_d, h->y_raw.p, 2 * Ls * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(h, hipMemcpyAsync(h->pin_d + 2 * Ls, h->cnt_raw.p, Ls * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+    if (h->world > 1)
+        for (int r = 0; r < h->world && r < 64; ++r)
+            HIPCHK(h, hipMemcpyAsync(h->pin_d + 3 * Ls + 16 + r, h->stats_all + (size_t)r * (size_t)icm_stats_stride(h) + 3 * Ls, sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->ev_copied, h->copy_stream));
+    h->map_copy_pending = true;
     return ICM_OK;
 }
 
@@ -512,7 +539,16 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
             if (!(colour == col || colour < 0)) continue;
             if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_colour<true><<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, col)));
             else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_colour<false><<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, col)));
-            else TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_threads(nw), kBlock, 0, h->stream>>>(a, col)));
+            else {
+                // experiment knob: ICM_SOLVE_VARIANT = "<lanes per wave>x<waves per SIMD>"
+                int lpw = 64, wpe = 1;
+                if (const char* ev = getenv("ICM_SOLVE_VARIANT")) sscanf(ev, "%dx%d", &lpw, &wpe);
+#define SOLVE_M(LPW, WPE) TIMED(h, KID_SOLVE, (k_solve_m_colour<LPW, WPE><<<nblocks_waves((nw + LPW - 1) / LPW), kBlock, 0, h->stream>>>(a, col)))
+#define SOLVE_W(LPW) do { if (wpe >= 4) SOLVE_M(LPW, 4); else if (wpe >= 2) SOLVE_M(LPW, 2); else SOLVE_M(LPW, 1); } while (0)
+                if (lpw <= 8) SOLVE_W(8); else if (lpw <= 16) SOLVE_W(16); else if (lpw <= 32) SOLVE_W(32); else SOLVE_W(64);
+#undef SOLVE_W
+#undef SOLVE_M
+            }
         }
     } else {
         FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: unknown schedule");
@@ -530,22 +566,18 @@ int icm_sweep_finish(icm_handle* h) {
     }
     HIPCHK(h, hipSetDevice(h->device));
     const size_t L = (size_t)h->cfg.L;
+    if (!h->map_copy_pending) FAIL(h, ICM_ERR_ARG, "icm_sweep_finish: call icm_sweep_targets first");
+    HIPCHK(h, hipEventSynchronize(h->ev_copied));  // the solves may still be running
+    h->map_copy_pending = false;
     // total number of landmarks created this sweep, over all ranks
     int64_t n_new = h->n_new_loc;
     if (h->world > 1) {
+        if (h->world > 64) FAIL(h, ICM_ERR_UNSUPPORTED, "more than 64 ranks");
         n_new = 0;
-        for (int r = 0; r < h->world; ++r) {
-            double v = 0.0;
-            HIPCHK(h, hipMemcpyAsync(&v, h->stats_all + (size_t)r * (size_t)icm_stats_stride(h) + 3 * L, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            n_new += (int64_t)v;
-        }
+        for (int r = 0; r < h->world; ++r) n_new += (int64_t)h->pin_d[3 * L + 16 + (size_t)r];
     }
     h->lact_raw = h->lact0 + n_new;
     if (h->lact_raw > (int64_t)L) FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L");
-    HIPCHK(h, hipMemcpyAsync(h->pin_d, h->y_raw.p, 2 * L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->pin_d + 2 * L, h->cnt_raw.p, L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     h->h_yraw.assign(h->pin_d, h->pin_d + 2 * L);
     h->h_cntraw.assign(h->pin_d + 2 * L, h->pin_d + 3 * L);
     std::vector<double> yo(2 * L), co(L);

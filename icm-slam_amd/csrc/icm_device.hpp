@@ -287,93 +287,92 @@ __device__ __forceinline__ double amax3(const Vtx& a, const Vtx& b) {
 // rho=1 chi=2 psi=sigma=0.5, xatol=1e-3 AND fatol=1e-4, maxiter=maxfun=600, initial simplex
 // x0 with one coordinate *1.05 (0.00025 if it is exactly 0), one stable sort per iteration.
 // A function call beyond maxfun aborts the iteration like SciPy's _MaxFuncCallError.
-// Written as a state machine around ONE call site of f, so the (large) energy body exists
-// once in the kernel instead of once per simplex move.
+//
+// Shaped for SIMT: lanes that solve different poses stay in lockstep per ITERATION -- one
+// shared call site for the reflection, one for the second point of the iteration (expansion
+// or either contraction; lanes that accepted the reflection idle through it), a rarely
+// entered shrink loop, and one for the four initial vertices.  Four inlined copies of the
+// energy in total, and no per-evaluation state dispatch.
 // out = {x, y, theta, f, nit, nfev}.
 template <class F>
 __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double st, double out[6]) {
     const int maxfun = 600, maxiter = 600;
     const double xatol = 1e-3, fatol = 1e-4;
     const double grow = 1 + 0.05;
-    enum { S_INIT, S_REFLECT, S_EXPAND, S_OUTSIDE, S_INSIDE, S_SHRINK };
     Vtx v0{sx, sy, st, 0.0};
     Vtx v1{sx != 0.0 ? grow * sx : 0.00025, sy, st, 0.0};
     Vtx v2{sx, sy != 0.0 ? grow * sy : 0.00025, st, 0.0};
     Vtx v3{sx, sy, st != 0.0 ? grow * st : 0.00025, 0.0};
-    Vtx r{0, 0, 0, 0}, cur = v0;
-    double bx = 0, by = 0, bt = 0;
-    int state = S_INIT, idx = 0, nfev = 0, it = 1;
-    for (;;) {
-        if (nfev >= maxfun) {  // only reachable inside an iteration: abort it, sort, stop
-            sort4(v0, v1, v2, v3);
-            break;
-        }
-        cur.f = f(cur.x, cur.y, cur.t);
-        ++nfev;
-        bool end_iter = false, shrink = false;
-        if (state == S_INIT || state == S_SHRINK) {
-            if (idx == 0) v0.f = cur.f; else if (idx == 1) v1.f = cur.f; else if (idx == 2) v2.f = cur.f; else v3.f = cur.f;
-            ++idx;
-            if (idx < 4) {
-                if (state == S_SHRINK) {  // sim[j] = sim[0] + sigma (sim[j] - sim[0]), then evaluate it
-                    if (idx == 2) {
-                        v2.x = v0.x + 0.5 * (v2.x - v0.x); v2.y = v0.y + 0.5 * (v2.y - v0.y); v2.t = v0.t + 0.5 * (v2.t - v0.t);
-                    } else {
-                        v3.x = v0.x + 0.5 * (v3.x - v0.x); v3.y = v0.y + 0.5 * (v3.y - v0.y); v3.t = v0.t + 0.5 * (v3.t - v0.t);
-                    }
-                }
-                if (idx == 1) cur = v1; else if (idx == 2) cur = v2; else cur = v3;
-                continue;
-            }
-            if (state == S_SHRINK) end_iter = true;
-            else sort4(v0, v1, v2, v3);
-        } else if (state == S_REFLECT) {
-            r = cur;
-            if (r.f < v0.f) {
-                cur = Vtx{3 * bx - 2 * v3.x, 3 * by - 2 * v3.y, 3 * bt - 2 * v3.t, 0.0};
-                state = S_EXPAND;
-                continue;
-            } else if (r.f < v2.f) {
-                v3 = r;
-                end_iter = true;
-            } else if (r.f < v3.f) {
-                cur = Vtx{1.5 * bx - 0.5 * v3.x, 1.5 * by - 0.5 * v3.y, 1.5 * bt - 0.5 * v3.t, 0.0};
-                state = S_OUTSIDE;
-                continue;
-            } else {
-                cur = Vtx{0.5 * bx + 0.5 * v3.x, 0.5 * by + 0.5 * v3.y, 0.5 * bt + 0.5 * v3.t, 0.0};
-                state = S_INSIDE;
-                continue;
-            }
-        } else if (state == S_EXPAND) {
-            v3 = (cur.f < r.f) ? cur : r;
-            end_iter = true;
-        } else if (state == S_OUTSIDE) {
-            if (cur.f <= r.f) { v3 = cur; end_iter = true; } else shrink = true;
-        } else {  // S_INSIDE
-            if (cur.f < v3.f) { v3 = cur; end_iter = true; } else shrink = true;
-        }
-        if (shrink) {
-            v1.x = v0.x + 0.5 * (v1.x - v0.x); v1.y = v0.y + 0.5 * (v1.y - v0.y); v1.t = v0.t + 0.5 * (v1.t - v0.t);
-            cur = v1;
-            idx = 1;
-            state = S_SHRINK;
-            continue;
-        }
-        if (end_iter) {
-            ++it;
-            sort4(v0, v1, v2, v3);
-        }
-        // top of SciPy's while loop
-        if (!(nfev < maxfun && it < maxiter)) break;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        Vtx c = v0;
+        if (i == 1) c = v1;
+        if (i == 2) c = v2;
+        if (i == 3) c = v3;
+        const double fv = f(c.x, c.y, c.t);
+        if (i == 0) v0.f = fv;
+        if (i == 1) v1.f = fv;
+        if (i == 2) v2.f = fv;
+        if (i == 3) v3.f = fv;
+    }
+    int nfev = 4, it = 1;
+    sort4(v0, v1, v2, v3);
+    while (nfev < maxfun && it < maxiter) {
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
         if (dx <= xatol && df <= fatol) break;
-        bx = ((v0.x + v1.x) + v2.x) / 3.0;
-        by = ((v0.y + v1.y) + v2.y) / 3.0;
-        bt = ((v0.t + v1.t) + v2.t) / 3.0;
-        cur = Vtx{2 * bx - v3.x, 2 * by - v3.y, 2 * bt - v3.t, 0.0};
-        state = S_REFLECT;
+        const double bx = ((v0.x + v1.x) + v2.x) / 3.0;
+        const double by = ((v0.y + v1.y) + v2.y) / 3.0;
+        const double bt = ((v0.t + v1.t) + v2.t) / 3.0;
+        Vtx r{2 * bx - v3.x, 2 * by - v3.y, 2 * bt - v3.t, 0.0};
+        r.f = f(r.x, r.y, r.t);
+        ++nfev;
+        // second point of the iteration: 1 expansion, 2 outside, 3 inside contraction, 0 none
+        int kind = 0;
+        double ca = 0.0, cb = 0.0;  // t = ca * xbar + cb * sim[-1]
+        if (r.f < v0.f) { kind = 1; ca = 3.0; cb = -2.0; }
+        else if (r.f < v2.f) { kind = 0; }
+        else if (r.f < v3.f) { kind = 2; ca = 1.5; cb = -0.5; }
+        else { kind = 3; ca = 0.5; cb = 0.5; }
+        bool shrink = false, aborted = false;
+        if (kind != 0) {
+            if (nfev >= maxfun) {
+                aborted = true;
+            } else {
+                Vtx t{ca * bx + cb * v3.x, ca * by + cb * v3.y, ca * bt + cb * v3.t, 0.0};
+                t.f = f(t.x, t.y, t.t);
+                ++nfev;
+                if (kind == 1) v3 = (t.f < r.f) ? t : r;
+                else if (kind == 2) { if (t.f <= r.f) v3 = t; else shrink = true; }
+                else { if (t.f < v3.f) v3 = t; else shrink = true; }
+            }
+        } else {
+            v3 = r;
+        }
+        if (shrink) {
+#pragma unroll 1
+            for (int j = 1; j < 4; ++j) {
+                // sim[j] = sim[0] + sigma (sim[j] - sim[0]) is stored before the call that may abort
+                Vtx c = j == 1 ? v1 : (j == 2 ? v2 : v3);
+                c.x = v0.x + 0.5 * (c.x - v0.x); c.y = v0.y + 0.5 * (c.y - v0.y); c.t = v0.t + 0.5 * (c.t - v0.t);
+                const bool go = nfev < maxfun;
+                if (go) {
+                    c.f = f(c.x, c.y, c.t);
+                    ++nfev;
+                }
+                if (j == 1) v1 = c; else if (j == 2) v2 = c; else v3 = c;
+                if (!go) { aborted = true; break; }
+            }
+            sort4(v0, v1, v2, v3);
+        } else {
+            // only the last vertex changed: numpy's (insertion) argsort moves it left past the
+            // strictly larger ones
+            cswap(v2, v3);
+            cswap(v1, v2);
+            cswap(v0, v1);
+        }
+        if (aborted) break;
+        ++it;
     }
     out[0] = v0.x; out[1] = v0.y; out[2] = v0.t; out[3] = v0.f;
     out[4] = (double)it; out[5] = (double)nfev;

@@ -268,13 +268,16 @@ __global__ __launch_bounds__(kBlock) void k_prefilter(const double* __restrict__
 // cells, each row one contiguous range of the cell-sorted table.  label = column index of
 // the nearest landmark (first index on ties, like np.argmin), -1 if farther than dist_thr.
 // ---------------------------------------------------------------------------------------
+struct LmRec {      // one landmark of the cell-sorted table (32 B: one aligned gather)
+    double x, y;
+    int id, pad0, pad1, pad2;
+};
+
 struct GridView {
     double gx0, gy0, inv;
     int nx, ny;
     const int* __restrict__ cell_start;
-    const double* __restrict__ lx;
-    const double* __restrict__ ly;
-    const int* __restrict__ id;
+    const LmRec* __restrict__ lm;
 };
 
 __device__ __forceinline__ int grid_cell(double v, double g0, double inv, int n) {
@@ -292,24 +295,40 @@ __device__ __forceinline__ void pose_of(const double* __restrict__ x, const doub
     }
 }
 
+// Gated nearest landmark of the world point (wx, wy).  The three cell rows around the point
+// are three contiguous ranges of the cell-sorted table; they are walked as ONE loop so the
+// wave iterates max-over-lanes of the candidate COUNT (about 1.5 on average), not three
+// times max-over-lanes per row.  Candidates are ranked by squared distance; the reference
+// ranks sqrt(s) (cdist) with the first index winning ties, so two candidates whose squared
+// distances agree to 1e-15 relative are re-ranked exactly on sqrt.  One sqrt for the gate.
 __device__ __forceinline__ int assoc_grid(const GridView& g, double wx, double wy, double thr) {
     const int cx = grid_cell(wx, g.gx0, g.inv, g.nx), cy = grid_cell(wy, g.gy0, g.inv, g.ny);
     const int c0 = max(cx - 1, 0), c1 = min(cx + 1, g.nx - 1);
+    const int r0 = max(cy - 1, 0), r2 = min(cy + 1, g.ny - 1);
+    // rows r0, cy, r2 (clamped rows may coincide: count each distinct row once)
+    const int pa = g.cell_start[r0 * g.nx + c0], na = g.cell_start[r0 * g.nx + c1 + 1] - pa;
+    const int pb = g.cell_start[cy * g.nx + c0], nb = cy != r0 ? g.cell_start[cy * g.nx + c1 + 1] - pb : 0;
+    const int pc = g.cell_start[r2 * g.nx + c0], nc = r2 != cy ? g.cell_start[r2 * g.nx + c1 + 1] - pc : 0;
+    const int n = na + nb + nc;
     double best = __builtin_huge_val();
     int bid = -1;
-    for (int ry = max(cy - 1, 0); ry <= min(cy + 1, g.ny - 1); ++ry) {
-        const int p0 = g.cell_start[ry * g.nx + c0], p1 = g.cell_start[ry * g.nx + c1 + 1];
-        for (int p = p0; p < p1; ++p) {
-            const double dx = g.lx[p] - wx, dy = g.ly[p] - wy;
-            const double d = sqrt(dx * dx + dy * dy);
-            const int id = g.id[p];
-            if (d < best || (d == best && id < bid)) {
-                best = d;
-                bid = id;
+    for (int i = 0; i < n; ++i) {
+        const int p = i < na ? pa + i : (i < na + nb ? pb + (i - na) : pc + (i - na - nb));
+        const LmRec c = g.lm[p];
+        const double dx = c.x - wx, dy = c.y - wy;
+        const double s = dx * dx + dy * dy;
+        if (bid < 0 || s < best * (1.0 - 1e-15)) {
+            best = s;
+            bid = c.id;
+        } else if (s <= best * (1.0 + 1e-15)) {  // (near) tie: the reference's exact rule
+            const double d = sqrt(s), db = sqrt(best);
+            if (d < db || (d == db && c.id < bid)) {
+                best = s;
+                bid = c.id;
             }
         }
     }
-    return (bid >= 0 && !(best > thr)) ? bid : -1;
+    return (bid >= 0 && !(sqrt(best) > thr)) ? bid : -1;
 }
 
 // Brute-force form of the same association (all K landmarks, table tiled through LDS): the
@@ -387,6 +406,25 @@ __global__ __launch_bounds__(kBlock) void k_associate_brute(const double* __rest
 //   PRELABEL: labels come from `label` (brute-force cross-check) instead of the grid search
 //   DEBUG:    also write label[] and the beam -> entry map bloc[]
 // ---------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+}
+// One step of the segmented inclusive scan: fold in the (flag, count, sums) of the source
+// lane unless a run head was already seen at or before this lane.  Lanes without a source
+// (and rows masked out) receive zeros = the identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step(int& f, int& c, double& ax, double& ay) {
+    const int fu = dpp_mov_i<CTRL, ROW_MASK>(f), cu = dpp_mov_i<CTRL, ROW_MASK>(c);
+    const double xu = dpp_mov<CTRL, ROW_MASK>(ax), yu = dpp_mov<CTRL, ROW_MASK>(ay);
+    if (!f) {
+        c += cu;
+        ax += xu;
+        ay += yu;
+    }
+    f |= fu;
+}
+
 struct PoseTable {
     int key[kHash];
     int cnt[kHash];
@@ -447,24 +485,18 @@ __global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict
                 if (DEBUG) label[j] = lab;
             }
         }
-        // runs of equal labels: head flags, segmented inclusive scan of (1, bx, by)
-        const int prev = __shfl_up(lab, 1, kWave);
+        // runs of equal labels: head flags, segmented inclusive scan of (1, bx, by) in DPP
+        // form (row shifts inside each 16-lane row, then row_bcast:15 / :31 across rows)
+        const int prev = dpp_mov_i<0x138, 0xF>(lab);  // wave_shr:1
         const bool head = valid && (lane == 0 || prev != lab);
         int f = head ? 1 : 0, c = valid ? 1 : 0;
         double ax = bxx, ay = byy;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const int fu = __shfl_up(f, d, kWave), cu = __shfl_up(c, d, kWave);
-            const double xu = __shfl_up(ax, d, kWave), yu = __shfl_up(ay, d, kWave);
-            if (lane >= d) {
-                if (!f) {
-                    c += cu;
-                    ax += xu;
-                    ay += yu;
-                }
-                f |= fu;
-            }
-        }
+        seg_step<0x111, 0xF>(f, c, ax, ay);
+        seg_step<0x112, 0xF>(f, c, ax, ay);
+        seg_step<0x114, 0xF>(f, c, ax, ay);
+        seg_step<0x118, 0xF>(f, c, ax, ay);
+        seg_step<0x142, 0xA>(f, c, ax, ay);
+        seg_step<0x143, 0xC>(f, c, ax, ay);
         const int nexthead = __shfl_down(head ? 1 : 0, 1, kWave);
         const bool tail = valid && (lane == cn - 1 || nexthead);
         // run tails claim / find the slot of their label
@@ -923,9 +955,16 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
     }
 }
 
-// Red-black half sweep, moment form: one LANE per pose of the colour (64 poses per wave).
-__global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colour) {
-    const int w = blockIdx.x * kBlock + threadIdx.x;
+// Red-black half sweep, moment form: one LANE per pose of the colour.  LPW = active lanes
+// per wavefront: the solves are latency-bound (~60-130 dependent energy evaluations per
+// pose), so for moderate pose counts it pays to spread the poses over more, partly filled
+// wavefronts (more waves in flight per SIMD, shorter max-over-lanes tail); WPE = waves per
+// SIMD the register allocation must allow.
+template <int LPW, int WPE>
+__global__ __launch_bounds__(kBlock, WPE) void k_solve_m_colour(SolveArgs a, int colour) {
+    const int lane = lane_id();
+    if (lane >= LPW) return;
+    const int w = (blockIdx.x * kWavesPerBlock + wave_in_block()) * LPW + lane;
     int first = a.t_begin > 1 ? a.t_begin : 1;
     if ((first & 1) != colour) ++first;
     const int tg = first + 2 * w;

@@ -70,6 +70,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  A process must use ONE HIP
+    runtime: if ours (the system ROCm) were loaded first, a later `import torch` would find
+    "No HIP GPUs".  So when a torch wheel with a bundled runtime is installed, load that copy
+    first (same SONAME, so libicmslam_hip.so then binds to it); torch itself is not imported."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for d in spec.submodule_search_locations:
+        cand = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load():
     """Load libicmslam_hip.so and declare every entry point.  Raises ImportError if the
     library is missing -- build it with `python __graft_entry__.py` (or `make -C
@@ -81,6 +103,7 @@ def load():
         raise ImportError(
             "libicmslam_hip.so not found at %s: the HIP extension is not built and there is no "
             "CPU fallback. Run `make -C icm-slam_amd/csrc` (hipcc, --offload-arch=gfx950)." % LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
