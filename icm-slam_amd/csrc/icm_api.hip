@@ -88,7 +88,9 @@ struct icm_handle {
     // per-sweep
     DevBuf<int> label, bloc, st_label, st_k, nent, isnew, ent_off, new_rank, e_val, e_k, sval, lm_off, flags, scan_tot;
     DevBuf<unsigned> e_key, skey;
-    DevBuf<double> st_sx, st_sy, e_bx, e_by, e_wx, e_wy, e_wrx, e_wry, pose_c, pose_m, tgt_x, tgt_y, btx, bty;
+    DevBuf<double> st_sx, st_sy, pose_c, pose_m, btx, bty;
+    DevBuf<double2> e_b, e_wr, tgt;
+    DevBuf<EntW> e_w;
     DevBuf<double> stats_own, off_sx, off_sy, off_n, y_raw, cnt_raw, diag;
     DevBuf<unsigned char> sort_tmp;
     double* stats_all = nullptr;
@@ -96,6 +98,7 @@ struct icm_handle {
     int64_t E = 0, n_new_loc = 0, lact_raw = 0;
     int lact0 = 0;
     bool brute = false, debug = false, per_beam = false, assoc_kept = false;
+    double thr2 = 0.0;  // largest s with sqrt(s) <= dist_thr
     int form = 0;  // 0 moments (lane per pose), 1 per beam, 2 per entry (wave per pose)
     int *pin_i = nullptr;
     double* pin_d = nullptr;  // pinned staging: raw map download (3L)
@@ -187,6 +190,17 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
         delete h;
         return ICM_ERR_HIP;
     }
+    {   // exact squared gate: the largest double whose correctly rounded sqrt is <= dist_thr
+        const double thr = cfg->dist_thr;
+        double s2 = thr * thr;
+        if (thr >= 0.0 && std::isfinite(s2)) {
+            while (std::sqrt(s2) > thr) s2 = std::nextafter(s2, 0.0);
+            while (std::sqrt(std::nextafter(s2, INFINITY)) <= thr) s2 = std::nextafter(s2, INFINITY);
+        } else {
+            s2 = thr < 0.0 ? -1.0 : s2;
+        }
+        h->thr2 = s2;
+    }
     h->own_stream = true;
     h->h_counts.assign((size_t)cfg->L, 0.0);
     *out = h;
@@ -198,14 +212,14 @@ int icm_destroy(icm_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf<double>* dd[] = {&h->ranges, &h->cosb, &h->sinb, &h->odo, &h->u, &h->bd, &h->bx, &h->by, &h->x_own, &h->x0,
-                            &h->mapx, &h->mapy, &h->st_sx, &h->st_sy, &h->e_bx, &h->e_by, &h->e_wx, &h->e_wy, &h->e_wrx, &h->e_wry, &h->pose_m, &h->pose_c, &h->pose_s2, &h->tgt_x,
-                            &h->tgt_y, &h->btx, &h->bty, &h->stats_own, &h->off_sx, &h->off_sy, &h->off_n, &h->y_raw,
+                            &h->mapx, &h->mapy, &h->st_sx, &h->st_sy, &h->pose_m, &h->pose_c, &h->pose_s2, &h->btx, &h->bty, &h->stats_own, &h->off_sx, &h->off_sy, &h->off_n, &h->y_raw,
                             &h->cnt_raw, &h->diag};
     for (auto* b : dd) b->release();
     DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->label, &h->bloc, &h->st_label, &h->st_k,
                          &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags, &h->scan_tot};
     for (auto* b : di) b->release();
     h->g_lm.release();
+    h->e_b.release(); h->e_wr.release(); h->tgt.release(); h->e_w.release();
     h->e_key.release();
     h->skey.release();
     h->sort_tmp.release();
@@ -289,10 +303,8 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->st_k.reserve(nz)); HIPCHK(h, h->st_sx.reserve(nz)); HIPCHK(h, h->st_sy.reserve(nz));
     HIPCHK(h, h->btx.reserve(nz)); HIPCHK(h, h->bty.reserve(nz));
     HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz));
-    HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_bx.reserve(nz));
-    HIPCHK(h, h->e_by.reserve(nz)); HIPCHK(h, h->e_wx.reserve(nz)); HIPCHK(h, h->e_wy.reserve(nz));
-    HIPCHK(h, h->e_wrx.reserve(nz)); HIPCHK(h, h->e_wry.reserve(nz));
-    HIPCHK(h, h->tgt_x.reserve(nz)); HIPCHK(h, h->tgt_y.reserve(nz));
+    HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_b.reserve(nz));
+    HIPCHK(h, h->e_w.reserve(nz)); HIPCHK(h, h->e_wr.reserve(nz)); HIPCHK(h, h->tgt.reserve(nz));
     HIPCHK(h, h->scan_tot.reserve(2 * ((size_t)nloc / kScanTile + 2)));
     HIPCHK(h, h->nent.reserve((size_t)nloc + 1)); HIPCHK(h, h->isnew.reserve((size_t)nloc + 1));
     HIPCHK(h, h->ent_off.reserve((size_t)nloc + 1)); HIPCHK(h, h->new_rank.reserve((size_t)nloc + 1));
@@ -440,7 +452,7 @@ int icm_sweep_local(icm_handle* h) {
     h->assoc_kept = dbg;
 #define ASSOC_GROUP(PRE, DBG)                                                                                      \
     TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG><<<nbw, kBlock, 0, h->stream>>>(                             \
-        h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->label.p,       \
+        h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
         h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p)))
     if (h->brute) {
         TIMED(h, KID_ASSOC_BRUTE, (k_associate_brute<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->mapx.p, h->mapy.p, km, h->cfg.dist_thr, h->label.p)));
@@ -463,7 +475,7 @@ int icm_sweep_local(icm_handle* h) {
         FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
     const int nlab = h->lact0 + (int)h->n_new_loc;
     const int E = (int)h->E;
-    TIMED(h, KID_COMPACT, (k_compact<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, h->e_key.p, h->e_val.p, h->e_k.p, h->e_bx.p, h->e_by.p, h->e_wx.p, h->e_wy.p, h->e_wrx.p, h->e_wry.p, h->pose_c.p)));
+    TIMED(h, KID_COMPACT, (k_compact<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, h->e_key.p, h->e_val.p, h->e_k.p, h->e_b.p, h->e_w.p, h->e_wr.p, h->pose_c.p)));
     int bits = 1;
     while ((1ll << bits) < (int64_t)nlab + 1) ++bits;
     size_t tmp_bytes = h->sort_tmp.cap;
@@ -472,7 +484,7 @@ int icm_sweep_local(icm_handle* h) {
     TIMED(h, KID_LM_BOUNDS, (k_lm_bounds<<<nblocks_threads(nlab + 1), kBlock, 0, h->stream>>>(h->skey.p, E, nlab, h->lm_off.p)));
     if (h->world > 1) {
         double* stats_mine = h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h);
-        TIMED(h, KID_LM_TOTALS, (k_lm_scan<true><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_k.p, h->e_wx.p, h->e_wy.p, nullptr, nullptr, nullptr, nullptr, nullptr, stats_mine, nullptr, nullptr)));
+        TIMED(h, KID_LM_TOTALS, (k_lm_scan<true><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, nullptr, nullptr, nullptr, nullptr, stats_mine, nullptr, nullptr)));
         k_set_header<<<1, 1, 0, h->stream>>>(stats_mine, L, (double)h->n_new_loc, 0.0);
     }
     HIPCHK(h, hipGetLastError());
@@ -489,14 +501,14 @@ int icm_sweep_targets(icm_handle* h) {
     const int nlab = h->lact0 + (int)h->n_new_loc;
     if (h->world > 1) {
         TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
-        TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_k.p, h->e_wx.p, h->e_wy.p, h->off_sx.p, h->off_sy.p, h->off_n.p, h->tgt_x.p, h->tgt_y.p, nullptr, nullptr, nullptr)));
+        TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, h->off_sx.p, h->off_sy.p, h->off_n.p, h->tgt.p, nullptr, nullptr, nullptr)));
     } else {
-        TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_k.p, h->e_wx.p, h->e_wy.p, nullptr, nullptr, nullptr, h->tgt_x.p, h->tgt_y.p, nullptr, h->y_raw.p, h->cnt_raw.p)));
+        TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, nullptr, nullptr, nullptr, h->tgt.p, nullptr, h->y_raw.p, h->cnt_raw.p)));
     }
     if (h->form == 0)
-        TIMED(h, KID_POSE_MOMENTS, (k_pose_moments<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->ent_off.p, h->e_k.p, h->e_wrx.p, h->e_wry.p, h->tgt_x.p, h->tgt_y.p, h->pose_c.p, h->pose_m.p)));
+        TIMED(h, KID_POSE_MOMENTS, (k_pose_moments<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->ent_off.p, h->e_k.p, h->e_wr.p, h->tgt.p, h->pose_c.p, h->pose_m.p)));
     if (h->assoc_kept)
-        TIMED(h, KID_BEAM_TARGETS, (k_beam_targets<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->bloc.p, h->tgt_x.p, h->tgt_y.p, h->btx.p, h->bty.p)));
+        TIMED(h, KID_BEAM_TARGETS, (k_beam_targets<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->bloc.p, h->tgt.p, h->btx.p, h->bty.p)));
     HIPCHK(h, hipGetLastError());
     // The raw map (and, sharded, the ranks' new-landmark counts) is final here: start its
     // download on the copy stream so that Mapa.filtrar on the host overlaps the pose solves.
@@ -523,8 +535,8 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     a.T = (int)h->T; a.t_begin = (int)h->t_begin; a.nloc = (int)h->nloc;
     a.boff = h->boff.p; a.bx = h->bx.p; a.by = h->by.p; a.btx = h->btx.p; a.bty = h->bty.p;
     a.per_beam = h->per_beam ? 1 : 0;
-    a.ent_off = h->ent_off.p; a.e_k = h->e_k.p; a.e_bx = h->e_bx.p; a.e_by = h->e_by.p;
-    a.tgt_x = h->tgt_x.p; a.tgt_y = h->tgt_y.p; a.pose_c = h->pose_c.p; a.pose_m = h->pose_m.p;
+    a.ent_off = h->ent_off.p; a.e_k = h->e_k.p; a.e_b = h->e_b.p;
+    a.tgt = h->tgt.p; a.pose_c = h->pose_c.p; a.pose_m = h->pose_m.p;
     a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
     a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
     a.diag = h->diag.p;

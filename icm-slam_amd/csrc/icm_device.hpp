@@ -85,6 +85,8 @@ struct Items {
     const int* __restrict__ kw;
     double cxx, cxy, cyy;
     int n;
+    const double2* __restrict__ b2;  // entries form: (mean body x, y) and (target x, y) records
+    const double2* __restrict__ t2;
 };
 
 // One item held in registers (entries form, n <= 64: lane i owns entry i).
@@ -107,13 +109,20 @@ __device__ __forceinline__ double obs_energy(const SolveCtx& c, const Items& it,
     double ct, st;
     sincos(a, &st, &ct);
     double acc = 0.0;
-    for (int j = lane; j < it.n; j += kWave) {
-        const double bx = it.bx[j], by = it.by[j];
-        const double dx = (px + (bx * ct - by * st)) - it.tx[j];
-        const double dy = (py + (bx * st + by * ct)) - it.ty[j];
-        double e = (dx * c.Q0) * dx + (dy * c.Q1) * dy;
-        if (it.kw) e *= (double)it.kw[j];
-        acc += e;
+    if (it.kw) {  // entries form
+        for (int j = lane; j < it.n; j += kWave) {
+            const double2 b = it.b2[j], t = it.t2[j];
+            const double dx = (px + (b.x * ct - b.y * st)) - t.x;
+            const double dy = (py + (b.x * st + b.y * ct)) - t.y;
+            acc += ((dx * c.Q0) * dx + (dy * c.Q1) * dy) * (double)it.kw[j];
+        }
+    } else {      // one term per kept beam
+        for (int j = lane; j < it.n; j += kWave) {
+            const double bx = it.bx[j], by = it.by[j];
+            const double dx = (px + (bx * ct - by * st)) - it.tx[j];
+            const double dy = (py + (bx * st + by * ct)) - it.ty[j];
+            acc += (dx * c.Q0) * dx + (dy * c.Q1) * dy;
+        }
     }
     acc = wave_sum(acc);
     return it.kw ? acc + scatter_term(c, it, ct, st) : acc;

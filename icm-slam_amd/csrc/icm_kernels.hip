@@ -298,10 +298,13 @@ __device__ __forceinline__ void pose_of(const double* __restrict__ x, const doub
 // Gated nearest landmark of the world point (wx, wy).  The three cell rows around the point
 // are three contiguous ranges of the cell-sorted table; they are walked as ONE loop so the
 // wave iterates max-over-lanes of the candidate COUNT (about 1.5 on average), not three
-// times max-over-lanes per row.  Candidates are ranked by squared distance; the reference
-// ranks sqrt(s) (cdist) with the first index winning ties, so two candidates whose squared
-// distances agree to 1e-15 relative are re-ranked exactly on sqrt.  One sqrt for the gate.
-__device__ __forceinline__ int assoc_grid(const GridView& g, double wx, double wy, double thr) {
+// times max-over-lanes per row.  Candidates are ranked by squared distance s.  The reference
+// ranks d = sqrt(s) (cdist) with the first index winning ties and gates on d > dist_thr:
+//   * sqrt is monotone, so the ranking can only differ when the two smallest s agree to a few
+//     ulps; that case (detected from the runner-up) is re-ranked exactly on sqrt;
+//   * d > thr  <=>  s > thr2, with thr2 = the largest double whose correctly rounded sqrt is
+//     <= thr (computed on the host), so the gate needs no sqrt either.
+__device__ __forceinline__ int assoc_grid(const GridView& g, double wx, double wy, double thr, double thr2) {
     const int cx = grid_cell(wx, g.gx0, g.inv, g.nx), cy = grid_cell(wy, g.gy0, g.inv, g.ny);
     const int c0 = max(cx - 1, 0), c1 = min(cx + 1, g.nx - 1);
     const int r0 = max(cy - 1, 0), r2 = min(cy + 1, g.ny - 1);
@@ -310,25 +313,37 @@ __device__ __forceinline__ int assoc_grid(const GridView& g, double wx, double w
     const int pb = g.cell_start[cy * g.nx + c0], nb = cy != r0 ? g.cell_start[cy * g.nx + c1 + 1] - pb : 0;
     const int pc = g.cell_start[r2 * g.nx + c0], nc = r2 != cy ? g.cell_start[r2 * g.nx + c1 + 1] - pc : 0;
     const int n = na + nb + nc;
-    double best = __builtin_huge_val();
+    double best = __builtin_huge_val(), second = __builtin_huge_val();
     int bid = -1;
     for (int i = 0; i < n; ++i) {
         const int p = i < na ? pa + i : (i < na + nb ? pb + (i - na) : pc + (i - na - nb));
         const LmRec c = g.lm[p];
         const double dx = c.x - wx, dy = c.y - wy;
         const double s = dx * dx + dy * dy;
-        if (bid < 0 || s < best * (1.0 - 1e-15)) {
+        if (s < best) {
+            second = best;
             best = s;
             bid = c.id;
-        } else if (s <= best * (1.0 + 1e-15)) {  // (near) tie: the reference's exact rule
-            const double d = sqrt(s), db = sqrt(best);
+        } else {
+            second = fmin(second, s);
+        }
+    }
+    if (second <= best * (1.0 + 1e-15)) {  // (near) tie: the reference's exact rule on sqrt
+        double db = __builtin_huge_val();
+        bid = -1;
+        for (int i = 0; i < n; ++i) {
+            const int p = i < na ? pa + i : (i < na + nb ? pb + (i - na) : pc + (i - na - nb));
+            const LmRec c = g.lm[p];
+            const double dx = c.x - wx, dy = c.y - wy;
+            const double d = sqrt(dx * dx + dy * dy);
             if (d < db || (d == db && c.id < bid)) {
-                best = s;
+                db = d;
                 bid = c.id;
             }
         }
+        return (bid >= 0 && !(db > thr)) ? bid : -1;
     }
-    return (bid >= 0 && !(sqrt(best) > thr)) ? bid : -1;
+    return (bid >= 0 && !(best > thr2)) ? bid : -1;
 }
 
 // Brute-force form of the same association (all K landmarks, table tiled through LDS): the
@@ -410,19 +425,15 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_mov_i(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
 }
-// One step of the segmented inclusive scan: fold in the (flag, count, sums) of the source
-// lane unless a run head was already seen at or before this lane.  Lanes without a source
-// (and rows masked out) receive zeros = the identity.
+// One step of the segmented inclusive scan of two doubles: fold in the partial sums of the
+// source lane when `take`.  Lanes without a source (and masked rows) read zeros.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void seg_step(int& f, int& c, double& ax, double& ay) {
-    const int fu = dpp_mov_i<CTRL, ROW_MASK>(f), cu = dpp_mov_i<CTRL, ROW_MASK>(c);
+__device__ __forceinline__ void seg_step(bool take, double& ax, double& ay) {
     const double xu = dpp_mov<CTRL, ROW_MASK>(ax), yu = dpp_mov<CTRL, ROW_MASK>(ay);
-    if (!f) {
-        c += cu;
+    if (take) {
         ax += xu;
         ay += yu;
     }
-    f |= fu;
 }
 
 struct PoseTable {
@@ -437,7 +448,7 @@ template <bool PRELABEL, bool DEBUG>
 __global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int t_begin, int nloc, const int* __restrict__ boff,
                                                         const double* __restrict__ bx, const double* __restrict__ by,
-                                                        GridView g, double thr, int* __restrict__ label,
+                                                        GridView g, double thr, double thr2, int* __restrict__ label,
                                                         int* __restrict__ bloc, int* __restrict__ st_label,
                                                         int* __restrict__ st_k, double* __restrict__ st_sbx,
                                                         double* __restrict__ st_sby, int* __restrict__ nent_out,
@@ -481,22 +492,26 @@ __global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict
             } else {
                 const double wx = (bxx * ct - byy * st) + px;
                 const double wy = (bxx * st + byy * ct) + py;
-                lab = assoc_grid(g, wx, wy, thr);
+                lab = assoc_grid(g, wx, wy, thr, thr2);
                 if (DEBUG) label[j] = lab;
             }
         }
-        // runs of equal labels: head flags, segmented inclusive scan of (1, bx, by) in DPP
-        // form (row shifts inside each 16-lane row, then row_bcast:15 / :31 across rows)
+        // runs of equal labels.  dist = distance of the lane to the head of its run (from
+        // the ballot of the head flags); the segmented inclusive scan of (bx, by) then adds
+        // the partial of lane - d exactly when dist >= d (DPP row shifts inside each 16-lane
+        // row, then row_bcast:15 / :31 across rows); the run's beam count is dist + 1.
         const int prev = dpp_mov_i<0x138, 0xF>(lab);  // wave_shr:1
         const bool head = valid && (lane == 0 || prev != lab);
-        int f = head ? 1 : 0, c = valid ? 1 : 0;
+        const unsigned long long hm = __ballot(head) & ((2ull << lane) - 1ull);
+        const int dist = lane - (63 - (int)__builtin_clzll(hm | 1ull));
+        const int c = dist + 1;
         double ax = bxx, ay = byy;
-        seg_step<0x111, 0xF>(f, c, ax, ay);
-        seg_step<0x112, 0xF>(f, c, ax, ay);
-        seg_step<0x114, 0xF>(f, c, ax, ay);
-        seg_step<0x118, 0xF>(f, c, ax, ay);
-        seg_step<0x142, 0xA>(f, c, ax, ay);
-        seg_step<0x143, 0xC>(f, c, ax, ay);
+        seg_step<0x111, 0xF>(dist >= 1, ax, ay);
+        seg_step<0x112, 0xF>(dist >= 2, ax, ay);
+        seg_step<0x114, 0xF>(dist >= 4, ax, ay);
+        seg_step<0x118, 0xF>(dist >= 8, ax, ay);
+        seg_step<0x142, 0xA>(dist > (lane & 15), ax, ay);   // run began in an earlier row
+        seg_step<0x143, 0xC>(dist > (lane & 31), ax, ay);   // run began in rows 0-1
         const int nexthead = __shfl_down(head ? 1 : 0, 1, kWave);
         const bool tail = valid && (lane == cn - 1 || nexthead);
         // run tails claim / find the slot of their label
@@ -581,6 +596,12 @@ __global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict
     }
 }
 
+// Running-mean term of one entry: sum of its beams' world points and their count.  One
+// 32-byte record so that the per-landmark gather touches one line per entry.
+struct EntW {
+    double wx, wy, k, pad;
+};
+
 // Entries -> pose-major compact arrays.  The gated-out group of a pose gets the fresh id
 // lact0 + (number of earlier poses that created a landmark) (phase B).
 // Per entry: count, mean body point (energy item), sum of world points k p + R sum b
@@ -593,10 +614,9 @@ __global__ __launch_bounds__(kBlock) void k_compact(const double* __restrict__ x
                                                     const int* __restrict__ st_k, const double* __restrict__ st_sbx,
                                                     const double* __restrict__ st_sby, const double* __restrict__ pose_s2,
                                                     unsigned* __restrict__ e_key, int* __restrict__ e_val,
-                                                    int* __restrict__ e_k, double* __restrict__ e_bx,
-                                                    double* __restrict__ e_by, double* __restrict__ e_wx,
-                                                    double* __restrict__ e_wy, double* __restrict__ e_wrx,
-                                                    double* __restrict__ e_wry, double* __restrict__ pose_c) {
+                                                    int* __restrict__ e_k, double2* __restrict__ e_b,
+                                                    EntW* __restrict__ e_w, double2* __restrict__ e_wr,
+                                                    double* __restrict__ pose_c) {
     const int lane = lane_id();
     const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (tl >= nloc) return;
@@ -613,13 +633,10 @@ __global__ __launch_bounds__(kBlock) void k_compact(const double* __restrict__ x
         e_key[e0 + q] = (unsigned)lab;
         e_val[e0 + q] = e0 + q;
         e_k[e0 + q] = k;
-        e_bx[e0 + q] = sbx / kd;
-        e_by[e0 + q] = sby / kd;
+        e_b[e0 + q] = make_double2(sbx / kd, sby / kd);
         const double rx = ct * sbx - st * sby, ry = st * sbx + ct * sby;  // R sum b
-        e_wx[e0 + q] = kd * px + rx;
-        e_wy[e0 + q] = kd * py + ry;
-        e_wrx[e0 + q] = rx / kd;
-        e_wry[e0 + q] = ry / kd;
+        e_w[e0 + q] = EntW{kd * px + rx, kd * py + ry, kd, 0.0};
+        e_wr[e0 + q] = make_double2(rx / kd, ry / kd);
         mxx += sbx * sbx / kd;
         mxy += sbx * sby / kd;
         myy += sby * sby / kd;
@@ -658,11 +675,10 @@ __global__ __launch_bounds__(kBlock) void k_lm_bounds(const unsigned* __restrict
 // ---------------------------------------------------------------------------------------
 template <bool TOTALS>
 __global__ __launch_bounds__(kBlock) void k_lm_scan(int nlab, int L, const int* __restrict__ lm_off,
-                                                    const int* __restrict__ sval, const int* __restrict__ e_k,
-                                                    const double* __restrict__ e_wx, const double* __restrict__ e_wy,
+                                                    const int* __restrict__ sval, const EntW* __restrict__ e_w,
                                                     const double* __restrict__ off_sx, const double* __restrict__ off_sy,
-                                                    const double* __restrict__ off_n, double* __restrict__ tgt_x,
-                                                    double* __restrict__ tgt_y, double* __restrict__ stats,
+                                                    const double* __restrict__ off_n, double2* __restrict__ tgt,
+                                                    double* __restrict__ stats,
                                                     double* __restrict__ y_raw, double* __restrict__ cnt_raw) {
     const int lane = lane_id();
     const int i = blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -683,9 +699,10 @@ __global__ __launch_bounds__(kBlock) void k_lm_scan(int nlab, int L, const int* 
             double vx = 0.0, vy = 0.0, vn = 0.0;
             if (valid) {
                 e = sval[p];
-                vx = e_wx[e];
-                vy = e_wy[e];
-                vn = (double)e_k[e];
+                const EntW w = e_w[e];
+                vx = w.wx;
+                vy = w.wy;
+                vn = w.k;
             }
 #pragma unroll
             for (int d = 1; d < kWave; d <<= 1) {
@@ -699,10 +716,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_scan(int nlab, int L, const int* 
             vx += cx;
             vy += cy;
             vn += cn;
-            if (!TOTALS && valid) {
-                tgt_x[e] = vx / vn;
-                tgt_y[e] = vy / vn;
-            }
+            if (!TOTALS && valid) tgt[e] = make_double2(vx / vn, vy / vn);
             cx = __shfl(vx, last, kWave);
             cy = __shfl(vy, last, kWave);
             cn = __shfl(vn, last, kWave);
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_prefix(const double* __restric
 // Target per kept beam: y[:, c] of scripts/ICM_ROS.py:152 (parity tests, per-beam energy).
 __global__ __launch_bounds__(kBlock) void k_beam_targets(int nloc, const int* __restrict__ boff,
                                                          const int* __restrict__ ent_off, const int* __restrict__ bloc,
-                                                         const double* __restrict__ tgt_x, const double* __restrict__ tgt_y,
+                                                         const double2* __restrict__ tgt,
                                                          double* __restrict__ btx, double* __restrict__ bty) {
     const int lane = lane_id();
     const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -780,8 +794,9 @@ __global__ __launch_bounds__(kBlock) void k_beam_targets(int nloc, const int* __
     const int e0 = ent_off[tl];
     for (int j = boff[tl] + lane; j < boff[tl + 1]; j += kWave) {
         const int e = e0 + bloc[j];
-        btx[j] = tgt_x[e];
-        bty[j] = tgt_y[e];
+        const double2 t = tgt[e];
+        btx[j] = t.x;
+        bty[j] = t.y;
     }
 }
 
@@ -798,7 +813,8 @@ struct SolveArgs {
     const int* boff;
     const double *bx, *by, *btx, *bty;
     const int *ent_off, *e_k;
-    const double *e_bx, *e_by, *tgt_x, *tgt_y, *pose_c, *pose_m;
+    const double2 *e_b, *tgt;
+    const double *pose_c, *pose_m;
     double dt, R0, R1, R2, Q0, Q1, cte;
     double* diag;         // optional (T,3): f, nit, nfev per pose
 };
@@ -843,18 +859,19 @@ __device__ __forceinline__ void solve_pose(const SolveArgs& a, int tg, const dou
     }
     double out[6];
     if (PER_BEAM) {
-        Items it{a.bx + j0, a.by + j0, a.btx + j0, a.bty + j0, nullptr, 0.0, 0.0, 0.0, n};
+        Items it{a.bx + j0, a.by + j0, a.btx + j0, a.bty + j0, nullptr, 0.0, 0.0, 0.0, n, nullptr, nullptr};
         nelder_mead3([&](double px, double py, double th) { return pose_energy(c, it, px, py, th, lane); }, sx, sy, st, out);
     } else {
         const int e0 = a.ent_off[tl], ne = a.ent_off[tl + 1] - e0;
-        Items it{a.e_bx + e0, a.e_by + e0, a.tgt_x + e0, a.tgt_y + e0, a.e_k + e0,
-                 a.pose_c[3 * (size_t)tl], a.pose_c[3 * (size_t)tl + 1], a.pose_c[3 * (size_t)tl + 2], ne};
+        Items it{nullptr, nullptr, nullptr, nullptr, a.e_k + e0,
+                 a.pose_c[3 * (size_t)tl], a.pose_c[3 * (size_t)tl + 1], a.pose_c[3 * (size_t)tl + 2], ne,
+                 a.e_b + e0, a.tgt + e0};
         // the usual case: at most one entry per lane, held in registers for the whole solve
         RegItem r{0.0, 0.0, 0.0, 0.0, 0.0};
         const bool inreg = ne <= kWave;
         if (inreg && lane < ne) {
             r.k = (double)it.kw[lane];
-            r.bx = it.bx[lane]; r.by = it.by[lane]; r.tx = it.tx[lane]; r.ty = it.ty[lane];
+            r.bx = it.b2[lane].x; r.by = it.b2[lane].y; r.tx = it.t2[lane].x; r.ty = it.t2[lane].y;
         }
         nelder_mead3([&](double px, double py, double th) {
             const double hh = inreg ? obs_energy_reg(c, it, r, px, py, th) : obs_energy(c, it, px, py, th, lane);
@@ -873,9 +890,8 @@ __device__ __forceinline__ void solve_pose(const SolveArgs& a, int tg, const dou
 // its entries; stored [17][nloc] so that the lane-per-pose solver reads them coalesced.
 __global__ __launch_bounds__(kBlock) void k_pose_moments(const double* __restrict__ x, const double* __restrict__ x0,
                                                          int t_begin, int nloc, const int* __restrict__ ent_off,
-                                                         const int* __restrict__ e_k, const double* __restrict__ e_wrx,
-                                                         const double* __restrict__ e_wry, const double* __restrict__ tgt_x,
-                                                         const double* __restrict__ tgt_y, const double* __restrict__ pose_c,
+                                                         const int* __restrict__ e_k, const double2* __restrict__ e_wr,
+                                                         const double2* __restrict__ tgt, const double* __restrict__ pose_c,
                                                          double* __restrict__ pose_m) {
     const int lane = lane_id();
     const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -886,8 +902,9 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments(const double* __restric
 #pragma unroll
     for (int q = 0; q < kMomentCount; ++q) m[q] = 0.0;
     for (int e = ent_off[tl] + lane; e < ent_off[tl + 1]; e += kWave) {
-        const double k = (double)e_k[e], wx = e_wrx[e], wy = e_wry[e];
-        const double rx = (px + wx) - tgt_x[e], ry = (py + wy) - tgt_y[e];
+        const double2 w = e_wr[e], tg = tgt[e];
+        const double k = (double)e_k[e], wx = w.x, wy = w.y;
+        const double rx = (px + wx) - tg.x, ry = (py + wy) - tg.y;
         m[0] += k; m[1] += k * wx; m[2] += k * wy; m[3] += k * rx; m[4] += k * ry;
         m[5] += k * wx * wx; m[6] += k * wy * wy; m[7] += k * wx * wy;
         m[8] += k * wx * rx; m[9] += k * wy * rx; m[10] += k * wx * ry; m[11] += k * wy * ry;
@@ -1043,7 +1060,7 @@ __global__ __launch_bounds__(kWave) void k_solve_one(OneArgs a) {
     c.dt = a.dt; c.R0 = a.R0; c.R1 = a.R1; c.R2 = a.R2; c.Q0 = a.Q0; c.Q1 = a.Q1; c.cte = a.cte;
     const double* p = a.p;
     make_ctx(c, a.two_sided, p + 3, p + 6, p + 9, p + 11, p + 13, p + 16, p + 19);
-    Items it{a.bx, a.by, a.tx, a.ty, nullptr, 0.0, 0.0, 0.0, a.n};
+    Items it{a.bx, a.by, a.tx, a.ty, nullptr, 0.0, 0.0, 0.0, a.n, nullptr, nullptr};
     double out[6] = {0, 0, 0, 0, 0, 0};
     if (a.energy_only == 2) {
         out[3] = obs_energy(c, it, p[0], p[1], p[2], lane);
