@@ -39,21 +39,24 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch):
     the kernel must read or write once, no re-reads.  nnz = kept beams, E = (pose, landmark)
     entries, nloc = poses of the shard, L = landmark capacity."""
     per_sweep = {
-        # read body x,y of every kept beam + pose; write one staged entry (label,k,sum bx,sum by)
-        # per distinct landmark of the scan
+        # read body x,y of every kept beam (16 B) + pose; write one staged entry
+        # (label 4, k 4, sum bx 8, sum by 8) per distinct landmark of the scan; counts/flags
         "k_assoc_group": nnz * 16 + E * 24 + nloc * (24 + 8 + 8),
         "k_associate_brute": nnz * (16 + 4) + nloc * 32,
-        # staged entries in; compact entries out (key,val,k,mean b,sum w); pose + scatter
-        "k_compact": E * 24 + E * 44 + nloc * (24 + 24 + 24 + 8),
+        # staged entries in (24); out: key 4, id 4, k 4, mean b 16, world sums 32, rotated mean 16;
+        # per pose: pose 24, second moments 24, scatter 24, offsets 8
+        "k_compact": E * 24 + E * 76 + nloc * 80,
         "radix_sort_pairs": E * 8 * 2 * 2,
         "k_lm_bounds": (L + 1) * 4,
-        "k_lm_scan_totals": E * (4 + 20) + L * (8 + 24),
+        "k_lm_scan_totals": E * (4 + 32) + L * (8 + 24),
         "k_stats_prefix": L * (24 + 24 + 24),
-        # sorted entry ids + gathered (k, sum wx, sum wy) in; target per entry out; raw map out
-        "k_lm_scan": E * (4 + 20 + 16) + L * (8 + 24),
+        # sorted entry ids 4 + gathered world-sum record 32 in; target 16 per entry out; raw map out
+        "k_lm_scan": E * (4 + 32 + 16) + L * (8 + 24),
         "k_beam_targets": nnz * (4 + 16) + E * 16,
-        # both colours together: (k, mean b, target) of every entry; pose in/out, odometry, u, scatter
-        "k_solve": E * 36 + nloc * (88 + 24 + 8),
+        # per entry: k 4, rotated mean 16, target 16; per pose: pose 24, scatter 24, 17 moments out
+        "k_pose_moments": E * 36 + nloc * (24 + 24 + 136 + 8),
+        # both colours together, per pose: 17 moments, own + 2 neighbour poses, odometry 72, u 32, pose out 24
+        "k_solve": nloc * (136 + 72 + 72 + 32 + 24 + 8),
         "k_scan": nloc * 16,
     }
     return per_sweep.get(kernel, 0) / max(nlaunch, 1)
