@@ -26,11 +26,11 @@ std::string g_create_err;
 
 enum KernelId {
     KID_PREFILTER = 0, KID_SCAN, KID_ASSOC_BRUTE, KID_ASSOC_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_TOTALS,
-    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_COUNT
+    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_FILTRAR, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_scan", "k_associate_brute", "k_assoc_group", "k_compact",
                                        "radix_sort_pairs", "k_lm_bounds", "k_lm_scan_totals", "k_stats_prefix",
-                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve"};
+                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_filtrar_grid"};
 
 template <class T>
 struct DevBuf {
@@ -80,8 +80,11 @@ struct icm_handle {
 
     // association grid
     Grid grid;
-    DevBuf<int> g_cell;
-    DevBuf<LmRec> g_lm;
+    DevBuf<int> g_cell, fl_cid, fl_cell_cnt, fl_cell_fill, fl_info;
+    DevBuf<LmRec> g_lm, fl_tbl;
+    DevBuf<GridParams> gpar;
+    DevBuf<double> fl_px, fl_py, fl_pc, counts_new;
+    bool h_map_valid = true, gpu_filtrar = true;
     std::vector<LmRec> h_lm;
     DevBuf<double> mapx, mapy;
 
@@ -218,7 +221,9 @@ int icm_destroy(icm_handle* h) {
     DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->label, &h->bloc, &h->st_label, &h->st_k,
                          &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags, &h->scan_tot};
     for (auto* b : di) b->release();
-    h->g_lm.release();
+    h->g_lm.release(); h->fl_tbl.release(); h->gpar.release();
+    h->fl_cid.release(); h->fl_cell_cnt.release(); h->fl_cell_fill.release(); h->fl_info.release();
+    h->fl_px.release(); h->fl_py.release(); h->fl_pc.release(); h->counts_new.release();
     h->e_b.release(); h->e_wr.release(); h->tgt.release(); h->e_w.release();
     h->e_key.release();
     h->skey.release();
@@ -312,9 +317,12 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(8));
     HIPCHK(h, h->stats_own.reserve(3 * L + 8)); HIPCHK(h, h->off_sx.reserve(L)); HIPCHK(h, h->off_sy.reserve(L));
     HIPCHK(h, h->off_n.reserve(L)); HIPCHK(h, h->y_raw.reserve(2 * L)); HIPCHK(h, h->cnt_raw.reserve(L));
-    HIPCHK(h, h->g_lm.reserve(L));
+    HIPCHK(h, h->g_lm.reserve(L)); HIPCHK(h, h->fl_tbl.reserve(L)); HIPCHK(h, h->gpar.reserve(1));
+    HIPCHK(h, h->fl_cid.reserve(L)); HIPCHK(h, h->fl_cell_cnt.reserve(8 * L + 4096 + 2)); HIPCHK(h, h->fl_cell_fill.reserve(8 * L + 4096 + 2));
+    HIPCHK(h, h->fl_info.reserve(8)); HIPCHK(h, h->fl_px.reserve(L)); HIPCHK(h, h->fl_py.reserve(L)); HIPCHK(h, h->fl_pc.reserve(L));
+    HIPCHK(h, h->counts_new.reserve(L));
     HIPCHK(h, h->mapx.reserve(L)); HIPCHK(h, h->mapy.reserve(L));
-    HIPCHK(h, h->g_cell.reserve(4 * L + 1024 + 2));
+    HIPCHK(h, h->g_cell.reserve(8 * L + 4096 + 2));
     size_t tmp_bytes = 0;
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, nz, 0, 32, h->stream));
     HIPCHK(h, h->sort_tmp.reserve(tmp_bytes + 256));
@@ -358,7 +366,10 @@ static int upload_map(icm_handle* h) {
         HIPCHK(h, hipMemcpyAsync(h->mapx.p, mx, (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->mapy.p, my, (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
+    GridParams gp{g.gx0, g.gy0, g.inv, g.nx, g.ny};
+    HIPCHK(h, hipMemcpyAsync(h->gpar.p, &gp, sizeof(gp), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors are reused
+    h->h_map_valid = true;
     return ICM_OK;
 }
 
@@ -447,7 +458,7 @@ int icm_sweep_local(icm_handle* h) {
     const int km = (int)std::min(h->K, h->lact);
     const int nbw = nblocks_waves(nloc);
     HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
-    GridView gv{h->grid.gx0, h->grid.gy0, h->grid.inv, h->grid.nx, h->grid.ny, h->g_cell.p, h->g_lm.p};
+    GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p};
     const bool dbg = h->debug || h->per_beam;
     h->assoc_kept = dbg;
 #define ASSOC_GROUP(PRE, DBG)                                                                                      \
@@ -520,6 +531,25 @@ int icm_sweep_targets(icm_handle* h) {
     if (h->world > 1)
         for (int r = 0; r < h->world && r < 64; ++r)
             HIPCHK(h, hipMemcpyAsync(h->pin_d + 3 * Ls + 16 + r, h->stats_all + (size_t)r * (size_t)icm_stats_stride(h) + 3 * Ls, sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+    if (h->gpu_filtrar) {
+        FiltrarArgs fa;
+        fa.y_raw = h->y_raw.p; fa.cnt_raw = h->cnt_raw.p; fa.stats_all = h->world > 1 ? h->stats_all : nullptr;
+        fa.L = L; fa.lact0 = h->lact0; fa.n_new_loc = (int)h->n_new_loc; fa.world = h->world; fa.stride = (int)icm_stats_stride(h);
+        fa.cota = h->cfg.cota; fa.thr = h->cfg.dist_thr; fa.max_cells = 8 * L + 4096;
+        fa.px = h->fl_px.p; fa.py = h->fl_py.p; fa.pc = h->fl_pc.p; fa.cid = h->fl_cid.p;
+        fa.cell_cnt = h->fl_cell_cnt.p; fa.cell_fill = h->fl_cell_fill.p; fa.tbl = h->fl_tbl.p;
+        fa.mapx = h->mapx.p; fa.mapy = h->mapy.p; fa.counts_new = h->counts_new.p;
+        fa.gpar = h->gpar.p; fa.g_cell = h->g_cell.p; fa.g_lm = h->g_lm.p; fa.info = h->fl_info.p;
+        if (h->timing) {  // serialised on the main stream so that the events bracket it
+            TIMED(h, KID_FILTRAR, (k_filtrar_grid<<<1, kFB, 0, h->stream>>>(fa)));
+            HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
+        } else {
+            k_filtrar_grid<<<1, kFB, 0, h->copy_stream>>>(fa);
+        }
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+    }
     HIPCHK(h, hipEventRecord(h->ev_copied, h->copy_stream));
     h->map_copy_pending = true;
     return ICM_OK;
@@ -592,11 +622,18 @@ int icm_sweep_finish(icm_handle* h) {
     if (h->lact_raw > (int64_t)L) FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L");
     h->h_yraw.assign(h->pin_d, h->pin_d + 2 * L);
     h->h_cntraw.assign(h->pin_d + 2 * L, h->pin_d + 3 * L);
+    if (h->gpu_filtrar && h->pin_i[9] == 0) {
+        // Mapa.filtrar and the search grid of the refined map were produced on the GPU
+        // (k_filtrar_grid); the refined map becomes the next mapa_viejo (scripts/ICM_ROS.py:311)
+        h->K = h->lact = h->pin_i[8];
+        h->h_map_valid = false;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return ICM_OK;
+    }
     std::vector<double> yo(2 * L), co(L);
     int64_t lact_new = 0;
     int rc = filtrar_host(h->cfg, h->h_yraw.data(), h->h_cntraw.data(), h->lact_raw, yo.data(), co.data(), &lact_new, h->err);
     if (rc) return rc;
-    // the refined map becomes the next mapa_viejo (scripts/ICM_ROS.py:311)
     h->K = lact_new;
     h->lact = lact_new;
     h->h_map.resize(2 * (size_t)lact_new);
@@ -606,6 +643,21 @@ int icm_sweep_finish(icm_handle* h) {
     }
     h->h_counts = co;
     return upload_map(h);
+}
+
+// Bring the host copy of the refined map / counters up to date (after GPU-side filtrar).
+static int sync_host_map(icm_handle* h) {
+    if (h->h_map_valid) return ICM_OK;
+    const size_t K = (size_t)h->K, L = (size_t)h->cfg.L;
+    h->h_map.assign(2 * K, 0.0);
+    h->h_counts.assign(L, 0.0);
+    if (K) {
+        HIPCHK(h, hipMemcpy(h->h_map.data(), h->mapx.p, K * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(h->h_map.data() + K, h->mapy.p, K * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(h, hipMemcpy(h->h_counts.data(), h->counts_new.p, L * sizeof(double), hipMemcpyDeviceToHost));
+    h->h_map_valid = true;
+    return ICM_OK;
 }
 
 int icm_sweep_device(icm_handle* h, int schedule) {
@@ -620,6 +672,10 @@ int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out,
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_get_state: no state");
     HIPCHK(h, hipSetDevice(h->device));
+    {
+        int rc = sync_host_map(h);
+        if (rc) return rc;
+    }
     const size_t T = (size_t)h->T, L = (size_t)h->cfg.L;
     if (x) {
         std::vector<double> xt(3 * T);
@@ -798,6 +854,12 @@ int icm_set_energy_form(icm_handle* h, int form) {
     if (form < 0 || form > 2) FAIL(h, ICM_ERR_ARG, "icm_set_energy_form: form must be 0, 1 or 2");
     h->form = form;
     h->per_beam = form == 1;
+    return ICM_OK;
+}
+
+int icm_set_gpu_filtrar(icm_handle* h, int on) {
+    if (!h) return ICM_ERR_ARG;
+    h->gpu_filtrar = on != 0;
     return ICM_OK;
 }
 

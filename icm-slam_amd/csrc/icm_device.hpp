@@ -156,18 +156,35 @@ __device__ __forceinline__ double obs_energy_reg(const SolveCtx& c, const Items&
 struct PoseMoments {
     double S, Swx, Swy, Srx, Sry, Swxx, Swyy, Swxy, Swxrx, Swyrx, Swxry, Swyry, Srxx, Sryy;
     double cxx, cxy, cyy;      // pooled within-entry scatter (body frame)
-    double pox, poy, co, so;   // expansion point: p_o, cos/sin th_o
+    double pox, poy, tho, co, so;   // expansion point: p_o, th_o, cos/sin th_o
 };
 constexpr int kMomentCount = 14;
 
+// sin d and cos d - 1 for |d| <= 0.25 by their Taylor polynomials (truncation < 1e-18), as
+// explicit fused multiply-adds (our own arithmetic: not part of the reference's expression
+// tree that -ffp-contract=off protects).
+__device__ __forceinline__ void small_sincosm1(double d, double& s, double& cm1) {
+    const double z = d * d;
+    double ps = __builtin_fma(z, -1.0 / 6227020800.0, 1.0 / 39916800.0);  // z^6/13!, z^5/11!
+    ps = __builtin_fma(z, ps, -1.0 / 362880.0);
+    ps = __builtin_fma(z, ps, 1.0 / 5040.0);
+    ps = __builtin_fma(z, ps, -1.0 / 120.0);
+    ps = __builtin_fma(z, ps, 1.0 / 6.0);
+    s = __builtin_fma(-(d * z), ps, d);                                     // d - d^3/6 + ...
+    double pc = __builtin_fma(z, 1.0 / 87178291200.0, -1.0 / 479001600.0);  // z^7/14!, z^6/12!
+    pc = __builtin_fma(z, pc, 1.0 / 3628800.0);
+    pc = __builtin_fma(z, pc, -1.0 / 40320.0);
+    pc = __builtin_fma(z, pc, 1.0 / 720.0);
+    pc = __builtin_fma(z, pc, -1.0 / 24.0);
+    pc = __builtin_fma(z, pc, 0.5);
+    cm1 = -(z * pc);                                                        // -d^2/2 + d^4/24 - ...
+}
+
+// Observation energy in moment form at (px, py) and heading th_o + d, given
+// al = cos d - 1 and be = sin d, and (for the scatter term) cos/sin of the heading.
 __device__ __forceinline__ double moments_energy(const SolveCtx& c, const PoseMoments& m, double px, double py,
-                                                 double cth, double sth) {
+                                                 double al, double be, double cth, double sth) {
     const double dx = px - m.pox, dy = py - m.poy;
-    const double sd = sth * m.co - cth * m.so;   // sin(th - th_o)
-    const double cd = cth * m.co + sth * m.so;   // cos(th - th_o)
-    const double den = 1.0 + cd;
-    const double al = den > 1e-3 ? -(sd * sd) / den : cd - 1.0;  // cos d - 1 without cancellation
-    const double be = sd;
     const double X = (((m.S * dx) * dx + (al * al) * m.Swxx) + ((be * be) * m.Swyy + m.Srxx)) +
                      2.0 * ((dx * ((al * m.Swx - be * m.Swy) + m.Srx) + al * (m.Swxrx - be * m.Swxy)) - be * m.Swyrx);
     const double Y = (((m.S * dy) * dy + (al * al) * m.Swyy) + ((be * be) * m.Swxx + m.Sryy)) +
@@ -179,12 +196,26 @@ __device__ __forceinline__ double moments_energy(const SolveCtx& c, const PoseMo
     return (c.Q0 * X + c.Q1 * Y) + sc;
 }
 
-// fun_xn / fun_x with h in moment form; one sincos per evaluation.
+// fun_xn / fun_x with h in moment form.  Trigonometry: the NM iterates stay within a fraction
+// of a radian of the pose's previous heading th_o, so sin d, cos d - 1 come from short
+// polynomials and cos th, sin th from the rotation of (cos th_o, sin th_o) by d; the generic
+// sincos path is kept for |d| > 0.25 (the initial simplex vertex th*1.05 of a long trajectory).
 __device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const PoseMoments& m, double px, double py,
                                                       double th) {
-    double cth, sth;
-    sincos(th, &sth, &cth);
-    const double hh = moments_energy(c, m, px, py, cth, sth);
+    const double dl = th - m.tho;
+    double cth, sth, al, be;
+    if (fabs(dl) <= 0.25) {
+        small_sincosm1(dl, be, al);
+        cth = m.co + (m.co * al - m.so * be);
+        sth = m.so + (m.so * al + m.co * be);
+    } else {
+        sincos(th, &sth, &cth);
+        be = sth * m.co - cth * m.so;                 // sin(th - th_o)
+        const double cd = cth * m.co + sth * m.so;    // cos(th - th_o)
+        const double den = 1.0 + cd;
+        al = den > 1e-3 ? -(be * be) / den : cd - 1.0;  // cos d - 1 without cancellation
+    }
+    const double hh = moments_energy(c, m, px, py, al, be, cth, sth);
     const double r0 = px - c.gax, r1 = py - c.gay, r2 = wrap_pi(th - c.gat);
     const double prevR = ((r0 * c.R0) * r0 + (r1 * c.R1) * r1) + (r2 * c.R2) * r2;
     const double dax = px - c.xax, day = py - c.xay;

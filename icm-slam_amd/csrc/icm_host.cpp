@@ -33,7 +33,7 @@ void build_grid(const double* mx, const double* my, int64_t K, double dist_thr, 
     // a hair larger than the gate so rounding in the cell computation can never push a
     // landmark at distance <= dist_thr two cells away
     double cell = dist_thr > 0.0 ? dist_thr * (1.0 + 1e-9) : 1.0;
-    const double max_cells = 4.0 * (double)K + 1024.0;
+    const double max_cells = 8.0 * (double)K + 4096.0;
     for (;;) {
         double nxd = std::floor((x1 - x0) / cell) + 1.0, nyd = std::floor((y1 - y0) / cell) + 1.0;
         if (nxd * nyd <= max_cells) {

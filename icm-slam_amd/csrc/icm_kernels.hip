@@ -273,9 +273,13 @@ struct LmRec {      // one landmark of the cell-sorted table (32 B: one aligned 
     int id, pad0, pad1, pad2;
 };
 
-struct GridView {
+struct GridParams {  // device resident: written by the host (icm_set_state) or by k_filtrar_grid
     double gx0, gy0, inv;
     int nx, ny;
+};
+
+struct GridView {
+    const GridParams* __restrict__ par;
     const int* __restrict__ cell_start;
     const LmRec* __restrict__ lm;
 };
@@ -304,14 +308,15 @@ __device__ __forceinline__ void pose_of(const double* __restrict__ x, const doub
 //     ulps; that case (detected from the runner-up) is re-ranked exactly on sqrt;
 //   * d > thr  <=>  s > thr2, with thr2 = the largest double whose correctly rounded sqrt is
 //     <= thr (computed on the host), so the gate needs no sqrt either.
-__device__ __forceinline__ int assoc_grid(const GridView& g, double wx, double wy, double thr, double thr2) {
-    const int cx = grid_cell(wx, g.gx0, g.inv, g.nx), cy = grid_cell(wy, g.gy0, g.inv, g.ny);
-    const int c0 = max(cx - 1, 0), c1 = min(cx + 1, g.nx - 1);
-    const int r0 = max(cy - 1, 0), r2 = min(cy + 1, g.ny - 1);
+__device__ __forceinline__ int assoc_grid(const GridView& g, const GridParams& gp, double wx, double wy, double thr,
+                                          double thr2) {
+    const int cx = grid_cell(wx, gp.gx0, gp.inv, gp.nx), cy = grid_cell(wy, gp.gy0, gp.inv, gp.ny);
+    const int c0 = max(cx - 1, 0), c1 = min(cx + 1, gp.nx - 1);
+    const int r0 = max(cy - 1, 0), r2 = min(cy + 1, gp.ny - 1);
     // rows r0, cy, r2 (clamped rows may coincide: count each distinct row once)
-    const int pa = g.cell_start[r0 * g.nx + c0], na = g.cell_start[r0 * g.nx + c1 + 1] - pa;
-    const int pb = g.cell_start[cy * g.nx + c0], nb = cy != r0 ? g.cell_start[cy * g.nx + c1 + 1] - pb : 0;
-    const int pc = g.cell_start[r2 * g.nx + c0], nc = r2 != cy ? g.cell_start[r2 * g.nx + c1 + 1] - pc : 0;
+    const int pa = g.cell_start[r0 * gp.nx + c0], na = g.cell_start[r0 * gp.nx + c1 + 1] - pa;
+    const int pb = g.cell_start[cy * gp.nx + c0], nb = cy != r0 ? g.cell_start[cy * gp.nx + c1 + 1] - pb : 0;
+    const int pc = g.cell_start[r2 * gp.nx + c0], nc = r2 != cy ? g.cell_start[r2 * gp.nx + c1 + 1] - pc : 0;
     const int n = na + nb + nc;
     double best = __builtin_huge_val(), second = __builtin_huge_val();
     int bid = -1;
@@ -475,6 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict
     double px, py, th;
     pose_of(x, x0, t_begin + tl, px, py, th);
     const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
+    const GridParams gp = *g.par;
     int nent = 0;
     bool overflow = false;
     __builtin_amdgcn_wave_barrier();
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict
             } else {
                 const double wx = (bxx * ct - byy * st) + px;
                 const double wy = (bxx * st + byy * ct) + py;
-                lab = assoc_grid(g, wx, wy, thr, thr2);
+                lab = assoc_grid(g, gp, wx, wy, thr, thr2);
                 if (DEBUG) label[j] = lab;
             }
         }
@@ -783,6 +789,235 @@ __global__ __launch_bounds__(kBlock) void k_stats_prefix(const double* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Phase D on the GPU: Mapa.filtrar (reference scripts/ICM_SLAM_tools.py:204-265) and the search
+// grid of the refined map, fused in ONE single-workgroup kernel (the map is a few thousand
+// landmarks: every step is a handful of items per thread, the cost is launch latency, so one
+// launch on a side stream, concurrent with the pose solves).
+//   1. prune landmarks seen < cota times (order preserving compaction)
+//   2. uniform grid (cell >= dist_thr) over the survivors, nearest other landmark of each
+//   3. no pair closer than dist_thr (the usual case): the refined map is the survivors, each
+//      as the reference's count-weighted mean of one term, (y*n)/n; build its search grid.
+//      Otherwise (merges, or coincident landmarks whose zero distance the reference replaces
+//      by the global maximum) set info[1] and leave the exact sequential label propagation
+//      (:246-253) to the host routine.
+// info: [0] survivors = new landmarks_actuales, [1] needs the host path, [2] pairs to merge.
+// ---------------------------------------------------------------------------------------
+constexpr int kFB = 1024;  // threads of the fused kernel
+
+struct FiltrarArgs {
+    const double* y_raw;    // (2,L)
+    const double* cnt_raw;  // (L)
+    const double* stats_all;  // sharded: per-rank headers hold the new-landmark counts
+    int L, lact0, n_new_loc, world, stride;
+    double cota, thr;
+    int max_cells;
+    // scratch
+    double *px, *py, *pc;
+    int *cid, *cell_cnt, *cell_fill;
+    LmRec* tbl;
+    // outputs
+    double *mapx, *mapy, *counts_new;
+    GridParams* gpar;
+    int* g_cell;
+    LmRec* g_lm;
+    int* info;
+};
+
+__device__ __forceinline__ int block_exscan_1024(int v, int* wsum, int& total) {
+    // exclusive scan of one int per thread over the 1024-thread block
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int u = __shfl_up(inc, d, kWave);
+        if (lane >= d) inc += u;
+    }
+    __syncthreads();
+    if (lane == kWave - 1) wsum[w] = inc;
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int q = 0; q < kFB / kWave; ++q) {
+        const int s = wsum[q];
+        if (q < w) pre += s;
+        tot += s;
+    }
+    total = tot;
+    return pre + inc - v;
+}
+
+// Grid over n points: parameters, cell-sorted record table (order inside a cell is arbitrary;
+// every consumer breaks ties on the landmark id explicitly).  `cell_min` = smallest cell edge.
+__device__ void block_build_grid(const double* __restrict__ x, const double* __restrict__ y, int n, double cell_min,
+                                 int max_cells, int* __restrict__ cid, int* __restrict__ cell_start,
+                                 int* __restrict__ cell_fill, LmRec* __restrict__ tbl, GridParams* __restrict__ gp_out,
+                                 double* red, int* wsum) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double x0 = __builtin_huge_val(), x1 = -__builtin_huge_val(), y0 = x0, y1 = x1;
+    for (int i = tid; i < n; i += kFB) {
+        x0 = fmin(x0, x[i]); x1 = fmax(x1, x[i]);
+        y0 = fmin(y0, y[i]); y1 = fmax(y1, y[i]);
+    }
+    __syncthreads();
+    red[tid] = x0; red[kFB + tid] = x1; red[2 * kFB + tid] = y0; red[3 * kFB + tid] = y1;
+    __syncthreads();
+    for (int d = kFB / 2; d > 0; d >>= 1) {
+        if (tid < d) {
+            red[tid] = fmin(red[tid], red[tid + d]);
+            red[kFB + tid] = fmax(red[kFB + tid], red[kFB + tid + d]);
+            red[2 * kFB + tid] = fmin(red[2 * kFB + tid], red[2 * kFB + tid + d]);
+            red[3 * kFB + tid] = fmax(red[3 * kFB + tid], red[3 * kFB + tid + d]);
+        }
+        __syncthreads();
+    }
+    x0 = red[0]; x1 = red[kFB]; y0 = red[2 * kFB]; y1 = red[3 * kFB];
+    __syncthreads();
+    double cell = cell_min > 0.0 ? cell_min : 1.0;
+    int nx = 1, ny = 1;
+    if (n > 0) {
+        for (;;) {
+            const double nxd = floor((x1 - x0) / cell) + 1.0, nyd = floor((y1 - y0) / cell) + 1.0;
+            if (nxd * nyd <= (double)max_cells) {
+                nx = (int)nxd;
+                ny = (int)nyd;
+                break;
+            }
+            cell *= 2.0;
+        }
+    } else {
+        x0 = y0 = 0.0;
+    }
+    const double inv = 1.0 / cell;
+    const int ncell = nx * ny, nall = ncell + 1;
+    for (int c = tid; c < nall; c += kFB) cell_start[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kFB) {
+        const int c = grid_cell(y[i], y0, inv, ny) * nx + grid_cell(x[i], x0, inv, nx);
+        cid[i] = c;
+        atomicAdd(&cell_start[c], 1);
+    }
+    __syncthreads();
+    // Exclusive scan of the cell counts.  Each of the 16 waves owns a contiguous segment of
+    // cells and sweeps it in coalesced 64-cell steps with an in-register wave scan and a
+    // running carry (no barrier inside); a second coalesced pass adds the segment offsets.
+    {
+        const int seg = ((nall + kFB / kWave - 1) / (kFB / kWave) + kWave - 1) / kWave * kWave;  // multiple of 64
+        const int lo = min(w * seg, nall), hi = min(lo + seg, nall);
+        int carry = 0;
+        for (int base = lo; base < hi; base += kWave) {
+            const int c = base + lane;
+            const int v = c < hi ? cell_start[c] : 0;
+            int inc = v;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const int u = __shfl_up(inc, d, kWave);
+                if (lane >= d) inc += u;
+            }
+            if (c < hi) cell_start[c] = carry + inc - v;
+            carry += __shfl(inc, kWave - 1, kWave);
+        }
+        if (lane == 0) wsum[w] = carry;
+        __syncthreads();
+        int off = 0;
+        for (int q = 0; q < w; ++q) off += wsum[q];
+        for (int base = lo; base < hi; base += kWave) {
+            const int c = base + lane;
+            if (c < hi) {
+                const int v = cell_start[c] + off;
+                cell_start[c] = v;
+                cell_fill[c] = v;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += kFB) {
+        const int p = atomicAdd(&cell_fill[cid[i]], 1);
+        tbl[p] = LmRec{x[i], y[i], i, 0, 0, 0};
+    }
+    if (tid == 0) *gp_out = GridParams{x0, y0, inv, nx, ny};
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
+    __shared__ double red[4 * kFB];
+    __shared__ int wsum[kFB / kWave];
+    __shared__ int s_cnt[2];
+    __shared__ GridParams s_gp;
+    const int tid = threadIdx.x;
+    // landmarks in use before the filter: lact0 + the new ones of all ranks
+    int lact = a.lact0 + a.n_new_loc;
+    if (a.world > 1) {
+        lact = a.lact0;
+        for (int r = 0; r < a.world; ++r) lact += (int)a.stats_all[(size_t)r * a.stride + 3 * (size_t)a.L];
+    }
+    lact = min(lact, a.L);
+    // 1. prune, keeping the order
+    int n = 0;
+    for (int base = 0; base < lact; base += kFB) {
+        const int i = base + tid;
+        const int keep = (i < lact && a.cnt_raw[i] >= a.cota) ? 1 : 0;
+        int tot;
+        const int pos = n + block_exscan_1024(keep, wsum, tot);
+        if (keep) {
+            a.px[pos] = a.y_raw[i];
+            a.py[pos] = a.y_raw[a.L + i];
+            a.pc[pos] = a.cnt_raw[i];
+        }
+        n += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        s_cnt[0] = 0;
+        s_cnt[1] = 0;
+    }
+    __syncthreads();
+    // 2. nearest other survivor (only those closer than dist_thr matter)
+    if (n > 1) {
+        // a coarse grid (4 x the gate) is enough for the pair check and keeps the cell arrays small
+        block_build_grid(a.px, a.py, n, 4.0 * a.thr * (1.0 + 1e-9), a.max_cells, a.cid, a.cell_cnt, a.cell_fill, a.tbl, &s_gp, red, wsum);
+        const GridParams gp = s_gp;
+        for (int i = tid; i < n; i += kFB) {
+            const double xi = a.px[i], yi = a.py[i];
+            const int cx = grid_cell(xi, gp.gx0, gp.inv, gp.nx), cy = grid_cell(yi, gp.gy0, gp.inv, gp.ny);
+            const int c0 = max(cx - 1, 0), c1 = min(cx + 1, gp.nx - 1);
+            bool close = false, same = false;
+            for (int ry = max(cy - 1, 0); ry <= min(cy + 1, gp.ny - 1); ++ry)
+                for (int p = a.cell_cnt[ry * gp.nx + c0]; p < a.cell_cnt[ry * gp.nx + c1 + 1]; ++p) {
+                    const LmRec c = a.tbl[p];
+                    if (c.id == i) continue;
+                    const double dx = xi - c.x, dy = yi - c.y;
+                    const double d = sqrt(dx * dx + dy * dy);
+                    same |= d == 0.0;
+                    close |= d < a.thr;
+                }
+            if (close) atomicAdd(&s_cnt[0], 1);
+            if (same) atomicAdd(&s_cnt[1], 1);
+        }
+        __syncthreads();
+    }
+    const int merges = s_cnt[0], coincident = s_cnt[1];
+    const bool host = n == 0 || merges > 0 || coincident > 0;
+    if (tid == 0) {
+        a.info[0] = n;
+        a.info[1] = host ? 1 : 0;
+        a.info[2] = merges;
+    }
+    if (host) return;
+    // 3. refined map = survivors; count-weighted mean of a single term is (y*n)/n (:258-260)
+    for (int i = tid; i < a.L; i += kFB) {
+        if (i < n) {
+            const double c = a.pc[i];
+            a.mapx[i] = (a.px[i] * c) / c;
+            a.mapy[i] = (a.py[i] * c) / c;
+            a.counts_new[i] = c;
+        } else {
+            a.counts_new[i] = 0.0;
+        }
+    }
+    __syncthreads();
+    block_build_grid(a.mapx, a.mapy, n, a.thr * (1.0 + 1e-9), a.max_cells, a.cid, a.g_cell, a.cell_fill, a.g_lm, a.gpar, red, wsum);
+}
+
 // Target per kept beam: y[:, c] of scripts/ICM_ROS.py:152 (parity tests, per-beam energy).
 __global__ __launch_bounds__(kBlock) void k_beam_targets(int nloc, const int* __restrict__ boff,
                                                          const int* __restrict__ ent_off, const int* __restrict__ bloc,
@@ -955,7 +1190,8 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
     m.cxx = pm[14 * st_]; m.cxy = pm[15 * st_]; m.cyy = pm[16 * st_];
     // expansion point = this pose's previous-sweep value (still in x: nobody else writes it)
     m.pox = a.x[3 * (size_t)tg]; m.poy = a.x[3 * (size_t)tg + 1];
-    sincos(a.x[3 * (size_t)tg + 2], &m.so, &m.co);
+    m.tho = a.x[3 * (size_t)tg + 2];
+    sincos(m.tho, &m.so, &m.co);
     double sx, sy, st;
     if (!last) {
         sx = (prev[0] + xp[0]) / 2.0; sy = (prev[1] + xp[1]) / 2.0; st = (prev[2] + xp[2]) / 2.0;

@@ -287,6 +287,9 @@ class SweepEngine:
         form = {"moments": 0, "beam": 1, "entry": 2}.get(form, form)
         self._chk(self.lib.icm_set_energy_form(self.h, int(form)))
 
+    def set_gpu_filtrar(self, on):
+        self._chk(self.lib.icm_set_gpu_filtrar(self.h, int(bool(on))))
+
     def set_brute_force(self, on):
         self._chk(self.lib.icm_set_brute_force(self.h, int(bool(on))))
 

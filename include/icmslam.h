@@ -168,6 +168,11 @@ int icm_set_debug(icm_handle *h, int on);
  * Forms 1 and 2 exist to cross-check form 0. */
 int icm_set_energy_form(icm_handle *h, int form);
 
+/* Where Mapa.filtrar runs inside a sweep: 1 (default) = fused GPU kernel `k_filtrar_grid`
+ * (falls back to the host routine when landmarks have to be merged), 0 = always the host
+ * routine icm_filtrar.  Same results. */
+int icm_set_gpu_filtrar(icm_handle *h, int on);
+
 /* ---- instrumentation -------------------------------------------------------------------- */
 /* When enabled, every kernel launch of a sweep is bracketed by HIP events on the handle's
  * stream; icm_kernel_time() returns accumulated ms and launch count per kernel name. */

@@ -183,3 +183,37 @@ def test_redblack_matches_oracle_redblack(engine, init_state):
     assert d.max() <= POSE_LOOSE and loose <= 4
     assert K == mref.shape[1]
     assert np.abs(mo[:, :K] - mref).max() <= MAP_TOL
+
+
+def test_gpu_filtrar_equals_host_filtrar(engine, init_state):
+    """Mapa.filtrar as the fused GPU kernel (k_filtrar_grid) vs the host routine, on the real
+    dataset and on a synthetic map with no merges: identical maps, counters and poses."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    x_init, map_init, lact = init_state
+    _, odo, _ = dataset()
+    res = []
+    for gpu in (True, False):
+        engine.set_gpu_filtrar(gpu)
+        engine.set_state(map_init, x_init, odo[:, 0], lact)
+        for _ in range(3):
+            engine.sweep_device("redblack")
+        res.append(engine.get_state())
+    engine.set_gpu_filtrar(True)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    wl = make_workload(1900, 100, 180)
+    eng = SweepEngine(ConfigICM(D=wl.config))
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    res = []
+    for gpu in (True, False):
+        eng.set_gpu_filtrar(gpu)
+        eng.set_state(wl.map_init, wl.x_init, wl.x0)
+        for _ in range(3):
+            eng.sweep_device("redblack")
+        res.append(eng.get_state())
+    eng.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    assert res[0][3] > 50
