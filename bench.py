@@ -176,6 +176,11 @@ def main():
         # k_filtrar_grid is one workgroup on a side stream, concurrent with the solves: not on
         # the critical path and not a bandwidth kernel, so it is never the roofline subject
         dom = max((k for k in kt if k != "k_filtrar_grid"), key=lambda k: kt[k][0])
+        per_kernel = {}
+        for k, (ms_k, n_k) in kt.items():
+            ab = algorithmic_bytes(k, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof)
+            per_kernel[k] = {"ms_per_launch": round(ms_k / n_k, 4), "launches_per_sweep": n_k / nroof,
+                             "GBps": round(ab / (ms_k / n_k * 1e-3) / 1e9, 1) if ab else None}
         ms, n = kt[dom]
         avg_ms = ms / n
         nl = n / nroof
@@ -192,7 +197,10 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_sweep": nl,
                 "algorithmic_bytes_per_launch": int(abytes),
-                "kernels_ms_per_sweep": {k: round(v[0] / nroof, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}}
+                "kernels_ms_per_sweep": {k: round(v[0] / nroof, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
+                "kernels": per_kernel,
+                "note": "k_solve is FP64-VALU/latency bound (one lane per pose, ~60 dependent energy evaluations), "
+                        "k_assoc_group is the HBM-streaming kernel; k_filtrar_grid runs on a side stream under the solves"}
         Kt = st["entries"] / max(eng.nloc, 1)
         sweep_bytes = survey_bytes_per_pose(B, Kt, K, T) * (T - 1)
         roof["sweep_algorithmic_GBps"] = round(sweep_bytes / (ms_per_step * 1e-3) / 1e9, 2)
