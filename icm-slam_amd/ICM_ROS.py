@@ -81,6 +81,26 @@ class ICM_ROS(ROS):
             self.mapa_obj.cant_obs_i = np.array(cant_obs_i, dtype=np.float64)
         self.iterations_flag = True
 
+    def inicializar_offline(self):
+        """ROS-free `inicializar_online` (reference scripts/ICM_ROS.py:47-100) on the loaded
+        sequence: the same causal pass -- first scan clustered into the first landmarks, then
+        predict / associate against the running map / one-sided solve per sample -- run by the
+        HIP library, followed by `Mapa.filtrar`.  Leaves `self.mapa_viejo`, `self.positions`
+        and `self.mapa_obj` exactly where the reference leaves them."""
+        if self.mediciones.size == 0:
+            self.load_data()
+        self.x0 = np.array([self.odometria[:, 0]]).T
+        eng = self._get_engine()
+        x, y, cnt, lact, _ = eng.init_pass(self.x0)
+        self.mapa_obj = Mapa(self.config)
+        self.mapa_obj.landmarks_actuales = lact
+        self.mapa_obj.cant_obs_i = cnt
+        yy = self.mapa_obj.filtrar(y)
+        yy = yy[:, :self.mapa_obj.landmarks_actuales]
+        self.mapa_viejo = copy(yy)
+        self.positions = copy(x)
+        self.iterations_flag = True
+
     def inicializar_online(self):
         """The live rosbridge pass of the reference (scripts/ICM_ROS.py:47-100) is sensor
         I/O and outside this build; recorded data go through load_data() +
@@ -205,10 +225,11 @@ if __name__ == "__main__":
     config = ConfigICM(sys.argv[1] if len(sys.argv) > 1 else "config_ros.yaml")
     ICM = ICM_ROS(config)
     ICM.load_data()
-    init = np.load(sys.argv[2]) if len(sys.argv) > 2 else None
-    if init is None:
-        raise SystemExit("usage: ICM_ROS.py config.yaml init_state.npz  (x_init, map_init)")
-    ICM.set_initial_state(init["x_init"], init["map_init"])
+    if len(sys.argv) > 2:
+        init = np.load(sys.argv[2])
+        ICM.set_initial_state(init["x_init"], init["map_init"])
+    else:
+        ICM.inicializar_offline()
     mapa_viejo = copy(ICM.mapa_viejo)
     x = copy(ICM.positions)
     for iteracionICM in range(config.N):

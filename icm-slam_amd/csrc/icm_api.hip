@@ -813,6 +813,61 @@ int icm_filtrar(const icm_config* cfg, const double* y, const double* counts, in
     return filtrar_host(*cfg, y, counts, lact, y_out, counts_out, lact_out, g_create_err);
 }
 
+int icm_cluster_first_scan(const double* pts, int64_t n, double t, int32_t* labels_out) {
+    if (!pts || !labels_out) {
+        g_create_err = "icm_cluster_first_scan: null argument";
+        return ICM_ERR_ARG;
+    }
+    return cluster_first_scan_host(pts, n, t, labels_out, g_create_err);
+}
+
+int icm_init_pass(icm_handle* h, const double* x0, double* y, double* counts, int64_t* lact, double* x_out) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->prefiltered) FAIL(h, ICM_ERR_ARG, "icm_init_pass: call icm_upload + icm_prefilter first");
+    if (!x0 || !y || !counts || !lact || !x_out) FAIL(h, ICM_ERR_ARG, "icm_init_pass: null pointer");
+    if (h->t_begin != 0 || h->nloc != h->T) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_init_pass: the causal pass is one chain; it needs the whole sequence on one GPU");
+    const size_t T = (size_t)h->T, L = (size_t)h->cfg.L;
+    if (*lact <= 0 || *lact > (int64_t)L) FAIL(h, ICM_ERR_ARG, "icm_init_pass: seed the map with the first scan's clusters (icm_cluster_first_scan)");
+    int maxb = 0;
+    for (size_t t = 0; t < T; ++t) maxb = std::max(maxb, h->h_boff[t + 1] - h->h_boff[t]);
+    maxb = std::max(maxb, 1);
+    const size_t lds = (size_t)maxb * (4 * sizeof(double) + sizeof(int));
+    if (lds > 160 * 1024) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_init_pass: too many kept beams per scan for the LDS staging");
+    HIPCHK(h, hipSetDevice(h->device));
+    DevBuf<double> dx, dy, dc;
+    DevBuf<int> di;
+    HIPCHK(h, dx.reserve(3 * T)); HIPCHK(h, dy.reserve(2 * L)); HIPCHK(h, dc.reserve(L)); HIPCHK(h, di.reserve(2));
+    std::vector<double> xt(3 * T, 0.0);
+    xt[0] = x0[0]; xt[1] = x0[1]; xt[2] = x0[2];
+    int hi[2] = {(int)*lact, 0};
+    HIPCHK(h, hipMemcpy(dx.p, xt.data(), 3 * T * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dy.p, y, 2 * L * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dc.p, counts, L * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(di.p, hi, 2 * sizeof(int), hipMemcpyHostToDevice));
+    InitArgs a;
+    a.x = dx.p; a.odo = h->odo.p; a.u = h->u.p; a.T = (int)T; a.boff = h->boff.p; a.bx = h->bx.p; a.by = h->by.p;
+    a.y = dy.p; a.cnt = dc.p; a.lact = di.p; a.L = (int)L; a.maxb = maxb; a.thr = h->cfg.dist_thr;
+    a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
+    a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom; a.flags = di.p + 1;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_init_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_init_pass<<<1, kWave, lds, h->stream>>>(a);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(hi, di.p, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(xt.data(), dx.p, 3 * T * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(y, dy.p, 2 * L * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(counts, dc.p, L * sizeof(double), hipMemcpyDeviceToHost));
+    dx.release(); dy.release(); dc.release(); di.release();
+    if (hi[1]) FAIL(h, ICM_ERR_INDEX, "init pass: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
+    *lact = hi[0];
+    for (size_t t = 0; t < T; ++t) {
+        x_out[t] = xt[3 * t];
+        x_out[T + t] = xt[3 * t + 1];
+        x_out[2 * T + t] = xt[3 * t + 2];
+    }
+    return ICM_OK;
+}
+
 int icm_enable_timing(icm_handle* h, int on) {
     if (!h) return ICM_ERR_ARG;
     h->timing = on != 0;

@@ -174,4 +174,131 @@ int filtrar_host(const icm_config& cfg, const double* y, const double* counts, i
     return ICM_OK;
 }
 
+// ---- first-scan clustering ---------------------------------------------------------------
+namespace {
+struct Link {
+    int a, b;
+    double h;
+};
+}  // namespace
+
+int cluster_first_scan_host(const double* pts, int64_t n64, double t, int32_t* labels, std::string& err) {
+    if (n64 <= 0 || n64 > 20000) {
+        err = "cluster_first_scan: need 1..20000 observations";
+        return ICM_ERR_ARG;
+    }
+    const int n = (int)n64;
+    if (n == 1) {
+        labels[0] = 0;
+        return ICM_OK;
+    }
+    auto dist = [&](int i, int j) {
+        const double dx = pts[2 * i] - pts[2 * j], dy = pts[2 * i + 1] - pts[2 * j + 1];
+        return std::sqrt(dx * dx + dy * dy);
+    };
+    // single linkage as SciPy builds it: Prim's walk from observation 0 ...
+    std::vector<Link> z((size_t)n - 1);
+    std::vector<char> merged((size_t)n, 0);
+    std::vector<double> D((size_t)n, std::numeric_limits<double>::infinity());
+    int x = 0;
+    for (int k = 0; k < n - 1; ++k) {
+        merged[(size_t)x] = 1;
+        double cur = std::numeric_limits<double>::infinity();
+        int y = -1;
+        for (int i = 0; i < n; ++i) {
+            if (merged[(size_t)i]) continue;
+            const double d = dist(x, i);
+            if (D[(size_t)i] > d) D[(size_t)i] = d;
+            if (D[(size_t)i] < cur) {
+                y = i;
+                cur = D[(size_t)i];
+            }
+        }
+        z[(size_t)k] = Link{x, y, cur};
+        x = y;
+    }
+    // ... links ordered by height (stable), then union-find labels, smaller id first
+    std::stable_sort(z.begin(), z.end(), [](const Link& p, const Link& q) { return p.h < q.h; });
+    std::vector<int> parent((size_t)(2 * n - 1));
+    for (int i = 0; i < 2 * n - 1; ++i) parent[(size_t)i] = i;
+    auto find = [&](int a) {
+        while (parent[(size_t)a] != a) a = parent[(size_t)a];
+        return a;
+    };
+    for (int i = 0; i < n - 1; ++i) {
+        int a = find(z[(size_t)i].a), b = find(z[(size_t)i].b);
+        if (a > b) std::swap(a, b);
+        z[(size_t)i].a = a;
+        z[(size_t)i].b = b;
+        parent[(size_t)a] = parent[(size_t)b] = n + i;
+    }
+    // inconsistency coefficient of every link over its depth-2 sub-tree (itself + child links)
+    std::vector<double> inc((size_t)n - 1, 0.0), mx((size_t)n - 1, 0.0);
+    for (int i = 0; i < n - 1; ++i) {
+        // SciPy's walk is post-order: left child link, right child link, the link itself
+        double hs[3];
+        int cnt = 0;
+        if (z[(size_t)i].a >= n) hs[cnt++] = z[(size_t)(z[(size_t)i].a - n)].h;
+        if (z[(size_t)i].b >= n) hs[cnt++] = z[(size_t)(z[(size_t)i].b - n)].h;
+        hs[cnt++] = z[(size_t)i].h;
+        double s = 0.0, ss = 0.0;
+        for (int q = 0; q < cnt; ++q) {
+            s += hs[q];
+            ss += hs[q] * hs[q];
+        }
+        const double var = cnt >= 2 ? (ss - s * s / cnt) / (cnt - 1) : (ss - s * s / cnt) / cnt;
+        const double sd = var > 0.0 ? std::sqrt(var) : 0.0;
+        if (sd > 0.0) inc[(size_t)i] = (z[(size_t)i].h - s / cnt) / sd;
+        double m = inc[(size_t)i];
+        if (z[(size_t)i].a >= n) m = std::max(m, mx[(size_t)(z[(size_t)i].a - n)]);
+        if (z[(size_t)i].b >= n) m = std::max(m, mx[(size_t)(z[(size_t)i].b - n)]);
+        mx[(size_t)i] = m;
+    }
+    // flat clusters: left-first depth-first walk; a node whose sub-tree is consistent leads one
+    std::vector<int> T((size_t)n, 0);
+    int ncl = 0;
+    struct Frame {
+        int node;
+        bool leader;  // this node or an ancestor leads a cluster
+        int stage;
+    };
+    std::vector<Frame> st;
+    st.push_back(Frame{n - 2, false, 0});
+    while (!st.empty()) {
+        Frame& f = st.back();
+        const Link& l = z[(size_t)f.node];
+        if (f.stage == 0) {
+            if (!f.leader && mx[(size_t)f.node] <= t) {
+                f.leader = true;
+                ++ncl;
+            }
+            f.stage = 1;
+            if (l.a >= n) {
+                const bool ld = f.leader;
+                st.push_back(Frame{l.a - n, ld, 0});
+                continue;
+            }
+        }
+        if (f.stage == 1) {
+            f.stage = 2;
+            if (l.b >= n) {
+                const bool ld = f.leader;
+                st.push_back(Frame{l.b - n, ld, 0});
+                continue;
+            }
+        }
+        if (l.a < n) {
+            if (!f.leader) ++ncl;
+            T[(size_t)l.a] = ncl;
+        }
+        if (l.b < n) {
+            if (!f.leader) ++ncl;
+            T[(size_t)l.b] = ncl;
+        }
+        st.pop_back();
+    }
+    for (int i = 0; i < n; ++i) labels[i] = T[(size_t)i] - 1;
+    return ICM_OK;
+}
+
 }  // namespace icm

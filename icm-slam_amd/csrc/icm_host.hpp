@@ -27,4 +27,10 @@ void build_grid(const double* map_x, const double* map_y, int64_t K, double dist
 int filtrar_host(const icm_config& cfg, const double* y, const double* counts, int64_t lact,
                  double* y_out, double* counts_out, int64_t* lact_out, std::string& err);
 
+// First-scan clustering of Mapa.actualizar's Lact == 0 branch (reference
+// scripts/ICM_SLAM_tools.py:160-165): fcluster(linkage(pdist(pts)), t) - 1, i.e. SciPy's single
+// linkage, depth-2 inconsistency coefficients and the 'inconsistent' flat-cluster rule.
+// pts is (n,2) row-major; labels_out[n] in 0..ncl-1.
+int cluster_first_scan_host(const double* pts, int64_t n, double t, int32_t* labels_out, std::string& err);
+
 }  // namespace icm

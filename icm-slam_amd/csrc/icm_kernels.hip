@@ -1282,6 +1282,127 @@ __global__ __launch_bounds__(kWave) void k_solve_sequential(SolveArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The causal initialisation pass (reference inicializar_online_process, scripts/ICM_ROS.py:102-119,
+// driven over a recorded sequence): for t = 1..T-1 predict with the unicycle model, project
+// the scan with the PREDICTED pose, associate against the RUNNING map (every landmark seen so
+// far, brute force like the reference's cdist/argmin), fold the scan into the running means
+// with the reference's recurrence y <- S/(n+k) + y n/(n+k) (scripts/ICM_SLAM_tools.py:194), then
+// solve the one-sided energy fun_x.  Each step depends on the previous one (pose AND map), so
+// this is one wavefront walking the sequence; lanes parallelise the beams of the current scan.
+// LDS per scan: label, world point and target of every kept beam.
+// ---------------------------------------------------------------------------------------
+struct InitArgs {
+    double* x;  // (T,3); x[0] = x0 on entry
+    const double* odo;
+    const double* u;
+    int T;
+    const int* boff;
+    const double *bx, *by;
+    double* y;    // (2,L) running map, in/out
+    double* cnt;  // (L) observation counts, in/out
+    int* lact;    // landmarks in use, in/out
+    int L, maxb;
+    double thr, dt, R0, R1, R2, Q0, Q1, cte;
+    int* flags;   // [0] = a new landmark would not fit in L (the reference raises IndexError)
+};
+
+__global__ __launch_bounds__(kWave) void k_init_pass(InitArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* lwx = reinterpret_cast<double*>(smem);
+    double* lwy = lwx + a.maxb;
+    double* ltx = lwy + a.maxb;
+    double* lty = ltx + a.maxb;
+    int* llab = reinterpret_cast<int*>(lty + a.maxb);
+    const int lane = lane_id();
+    int lact = *a.lact;
+    double xt[3] = {a.x[0], a.x[1], a.x[2]};
+    for (int t = 1; t < a.T; ++t) {
+        const double v = a.u[t - 1], w = a.u[(size_t)a.T + t - 1];
+        const double xc0 = xt[0] + a.dt * (cos(xt[2]) * v), xc1 = xt[1] + a.dt * (sin(xt[2]) * v), xc2 = xt[2] + a.dt * w;
+        const int j0 = a.boff[t], n = a.boff[t + 1] - j0;
+        if (n == 0) {  // no observation: keep the prediction (scripts/ICM_ROS.py:110-113)
+            xt[0] = xc0; xt[1] = xc1; xt[2] = xc2;
+        } else {
+            const double ct = cos(xc2 - kHalfPi), st = sin(xc2 - kHalfPi);
+            bool isnew = false;
+            for (int j = lane; j < n; j += kWave) {
+                const double bxx = a.bx[j0 + j], byy = a.by[j0 + j];
+                const double wx = (bxx * ct - byy * st) + xc0, wy = (bxx * st + byy * ct) + xc1;
+                double best = __builtin_huge_val();
+                int bid = -1;
+                for (int i = 0; i < lact; ++i) {
+                    const double dx = a.y[i] - wx, dy = a.y[a.L + i] - wy;
+                    const double d = sqrt(dx * dx + dy * dy);
+                    if (d < best) {
+                        best = d;
+                        bid = i;
+                    }
+                }
+                const int lab = (bid >= 0 && !(best > a.thr)) ? bid : -1;
+                isnew |= lab < 0;
+                lwx[j] = wx;
+                lwy[j] = wy;
+                llab[j] = lab;
+            }
+            if (__ballot(isnew) != 0ull) {  // all gated-out beams of the scan share ONE new label
+                if (lact >= a.L) {
+                    if (lane == 0) a.flags[0] = 1;
+                    break;
+                }
+                for (int j = lane; j < n; j += kWave)
+                    if (llab[j] < 0) llab[j] = lact;
+                ++lact;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // fold the scan into the running means: the first beam of each label sums its group
+            for (int j = lane; j < n; j += kWave) {
+                const int lab = llab[j];
+                bool leader = true;
+                for (int q = 0; q < j; ++q) leader &= llab[q] != lab;
+                if (leader) {
+                    double sx = 0.0, sy = 0.0;
+                    int k = 0;
+                    for (int q = j; q < n; ++q)
+                        if (llab[q] == lab) {
+                            sx += lwx[q];
+                            sy += lwy[q];
+                            ++k;
+                        }
+                    const double nn = a.cnt[lab], tot = nn + (double)k;
+                    a.y[lab] = sx / tot + a.y[lab] * nn / tot;
+                    a.y[a.L + lab] = sy / tot + a.y[a.L + lab] * nn / tot;
+                    a.cnt[lab] = tot;
+                }
+            }
+            __threadfence_block();
+            for (int j = lane; j < n; j += kWave) {  // y[:, c] after the update (scripts/ICM_ROS.py:117-118)
+                ltx[j] = a.y[llab[j]];
+                lty[j] = a.y[a.L + llab[j]];
+            }
+            __builtin_amdgcn_wave_barrier();
+            SolveCtx c;
+            c.dt = a.dt; c.R0 = a.R0; c.R1 = a.R1; c.R2 = a.R2; c.Q0 = a.Q0; c.Q1 = a.Q1; c.cte = a.cte;
+            const double ua[2] = {v, w}, zero3[3] = {0, 0, 0}, zero2[2] = {0, 0};
+            double oa[3], ot[3];
+            load3(a.odo, a.T, t - 1, oa);
+            load3(a.odo, a.T, t, ot);
+            make_ctx(c, 0, xt, zero3, ua, zero2, oa, ot, zero3);
+            Items it{a.bx + j0, a.by + j0, ltx, lty, nullptr, 0.0, 0.0, 0.0, n, nullptr, nullptr};
+            double out[6];
+            nelder_mead3([&](double px, double py, double th) { return pose_energy(c, it, px, py, th, lane); },
+                         c.gax, c.gay, c.gat, out);
+            xt[0] = out[0]; xt[1] = out[1]; xt[2] = out[2];
+        }
+        if (lane == 0) {
+            a.x[3 * (size_t)t] = xt[0];
+            a.x[3 * (size_t)t + 1] = xt[1];
+            a.x[3 * (size_t)t + 2] = xt[2];
+        }
+    }
+    if (lane == 0) *a.lact = lact;
+}
+
 // One explicit solve / energy evaluation (parity tests).  io: see icm_solve_one.
 struct OneArgs {
     int two_sided, energy_only, n;

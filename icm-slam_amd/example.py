@@ -1,9 +1,9 @@
 """Counterpart of the reference's `scripts/example.py`: the same driver loop
 (scripts/example.py:37-54), offline.  The reference needs a live rosbridge; here the recorded
-sequence named by `config.file` is loaded and the state of an initialisation pass is read
-from an .npz (`x_init`, `map_init`), e.g. tests/golden/init_pass.npz for data_IJAC2018.
+sequence named by `config.file` is loaded and `inicializar_offline()` runs the same
+initialisation pass on it.
 
-    python example.py [config.yaml] [init_state.npz] [data file]
+    python example.py [config.yaml] [data.mat|data.npz]
 """
 import sys
 from copy import deepcopy as copy
@@ -26,11 +26,8 @@ class My_method(ICM_ROS):
 if __name__ == '__main__':
     config = ConfigICM(sys.argv[1] if len(sys.argv) > 1 else 'config_default.yaml')
     ICM = ICM_ROS(config)
-    ICM.load_data(sys.argv[3] if len(sys.argv) > 3 else None)
-    if len(sys.argv) < 3:
-        raise SystemExit("usage: example.py config.yaml init_state.npz [data.mat|data.npz]")
-    init = np.load(sys.argv[2])
-    ICM.set_initial_state(init['x_init'], init['map_init'])
+    ICM.load_data(sys.argv[2] if len(sys.argv) > 2 else None)
+    ICM.inicializar_offline()
     if ICM.iterations_flag:
         mapa_viejo = copy(ICM.mapa_viejo)
         x = copy(ICM.positions)

@@ -59,6 +59,20 @@ def filtrar_map(config, y, counts, lact):
     return yo, co, int(lo.value)
 
 
+def cluster_first_scan(points, t):
+    """Flat clusters of the first scan (`Mapa.actualizar` with no landmark yet, reference
+    scripts/ICM_SLAM_tools.py:160-165): labels 0..ncl-1 of the (n,2) world points."""
+    lib = _lib.load()
+    pts = _f64(points)
+    if pts.ndim != 2 or pts.shape[1] != 2:
+        raise ValueError("points must be (n,2)")
+    lab = np.zeros(pts.shape[0], dtype=np.int32)
+    rc = lib.icm_cluster_first_scan(dptr(pts), pts.shape[0], float(t), iptr(lab))
+    if rc:
+        _raise(rc, lib.icm_last_error(None).decode())
+    return lab
+
+
 _PREFILTER_ENGINES = {}
 
 
@@ -173,6 +187,31 @@ class SweepEngine:
         self._chk(self.lib.icm_get_kept(self.h, lptr(off), iptr(bk), dptr(d), dptr(bx), dptr(by)))
         k = self.nnz
         return off, bk[:k], d[:k], bx[:k], by[:k]
+
+    # ---- initialisation pass ----------------------------------------------------------------
+    def init_pass(self, x0):
+        """The causal first pass over the uploaded sequence (reference inicializar_online,
+        scripts/ICM_ROS.py:57-100, ROS-free): scan 0 is clustered into the first landmarks, then
+        every pose is predicted, associated against the running map and solved (one-sided).
+        Returns (x_init (3,T), y_raw (2,L), counts (L), landmarks_actuales) BEFORE Mapa.filtrar."""
+        x0 = _f64(np.asarray(x0, dtype=np.float64).reshape(3))
+        off, bk, d, bx, by = self.kept_beams()
+        n0 = int(off[1] - off[0])
+        if n0 == 0:
+            raise ValueError("the first scan has no kept beam: nothing to seed the map with")
+        ct, st = np.cos(x0[2] - np.pi / 2.0), np.sin(x0[2] - np.pi / 2.0)
+        w = np.stack(((bx[:n0] * ct - by[:n0] * st) + x0[0], (bx[:n0] * st + by[:n0] * ct) + x0[1]), axis=1)
+        c = cluster_first_scan(w, self.config.dist_thr)
+        y = np.zeros((2, self.L))
+        cnt = np.zeros(self.L)
+        lact = int(c.max()) + 1
+        for i in range(lact):          # cluster centres and sizes (scripts/ICM_SLAM_tools.py:163-165)
+            y[:, i] = np.mean(w[c == i, :], axis=0)
+            cnt[i] = np.sum(c == i)
+        la = C.c_int64(lact)
+        x = np.zeros((3, self.T))
+        self._chk(self.lib.icm_init_pass(self.h, dptr(x0), dptr(y), dptr(cnt), C.byref(la), dptr(x)))
+        return x, y, cnt, int(la.value), c
 
     # ---- one sweep through host arrays -------------------------------------------------
     def sweep(self, mapa_viejo, x, x0, lact, schedule="sequential"):

@@ -145,6 +145,18 @@ int icm_energy_one(icm_handle *h, int two_sided, const double *x, const double *
                    const double *bx, const double *by, const double *tx, const double *ty,
                    int64_t n, double *out);
 
+/* ---- initialisation pass (the caller of the sweep's inputs) ----------------- */
+/* Flat clusters of the first scan's world points: Mapa.actualizar with Lact == 0 (reference
+ * scripts/ICM_SLAM_tools.py:160-165), i.e. fcluster(linkage(pdist(pts)), t) - 1 with SciPy's
+ * defaults (single linkage, 'inconsistent' criterion, depth 2).  Host only.  pts (n,2). */
+int icm_cluster_first_scan(const double *pts, int64_t n, double t, int32_t *labels_out);
+/* The causal pass of inicializar_online / inicializar_online_process (reference
+ * scripts/ICM_ROS.py:57-119) over the uploaded sequence: predict, associate against the running
+ * map, running-mean update, one-sided solve, for t = 1..T-1.
+ *   x0 [3]; y (2,L) / counts (L) / lact: the map seeded from scan 0, updated in place;
+ *   x_out [3*T] the initial poses.  Mapa.filtrar (icm_filtrar) is applied by the caller. */
+int icm_init_pass(icm_handle *h, const double *x0, double *y, double *counts, int64_t *lact, double *x_out);
+
 /* ---- host-side map prune/merge (no GPU needed) ----------------------------------------- */
 /* Mapa.filtrar (reference scripts/ICM_SLAM_tools.py:204-265): y (2,L) row-major, counts (L),
  * lact in/out.  y_out (2,L) zero padded, counts_out (L). */

@@ -468,3 +468,155 @@ def calc_cambio(y, mapa_viejo):
     scripts/ICM_SLAM_tools.py:490-495)."""
     md = np.amin(_pairwise_dist(mapa_viejo.T, y.T), axis=0)
     return np.amin(md), np.amax(md), np.mean(md)
+
+
+# ----------------------------------------------------------------------------------------
+# a5 + the online initialisation pass (SURVEY section 8f row 3; reference
+# scripts/ICM_ROS.py:47-119 driven ROS-free as in SURVEY Appendix D)
+# ----------------------------------------------------------------------------------------
+def single_linkage(pts):
+    """scipy.cluster.hierarchy.linkage(pdist(pts)) (method 'single'): Prim's MST walk from
+    point 0, links sorted by height with a stable sort, then union-find labelling where the
+    smaller cluster id goes first.  Returns Z (n-1,4) like SciPy."""
+    n = pts.shape[0]
+    d = _pairwise_dist(pts, pts)
+    Z = np.zeros((n - 1, 4))
+    merged = np.zeros(n, dtype=bool)
+    D = np.full(n, np.inf)
+    x = 0
+    for k in range(n - 1):
+        merged[x] = True
+        cur = np.inf
+        y = -1
+        for i in range(n):
+            if merged[i]:
+                continue
+            if D[i] > d[x, i]:
+                D[i] = d[x, i]
+            if D[i] < cur:
+                y, cur = i, D[i]
+        Z[k, 0], Z[k, 1], Z[k, 2] = x, y, cur
+        x = y
+    Z = Z[np.argsort(Z[:, 2], kind="mergesort")]
+    parent = list(range(2 * n - 1))
+    size = [1] * n + [0] * (n - 1)
+
+    def find(a):
+        while parent[a] != a:
+            a = parent[a]
+        return a
+
+    for i in range(n - 1):
+        a, b = find(int(Z[i, 0])), find(int(Z[i, 1]))
+        Z[i, 0], Z[i, 1] = (a, b) if a < b else (b, a)
+        parent[a] = parent[b] = n + i
+        size[n + i] = size[a] + size[b]
+        Z[i, 3] = size[n + i]
+    return Z
+
+
+def inconsistency(Z, depth=2):
+    """scipy.cluster.hierarchy.inconsistent(Z, d)[:, 3]: (h - mean)/std over the link heights
+    of the sub-tree down to `depth` levels (sample std from the sums-of-squares formula)."""
+    n = Z.shape[0] + 1
+    out = np.zeros(n - 1)
+    for i in range(n - 1):
+        # SciPy's walk is post-order: left child link, right child link, the link itself
+        hs = []
+
+        def walk(node, lev):
+            if lev < depth - 1:
+                for ch in (int(Z[node, 0]), int(Z[node, 1])):
+                    if ch >= n:
+                        walk(ch - n, lev + 1)
+            hs.append(Z[node, 2])
+        walk(i, 0)
+        cnt = len(hs)
+        s = sum(hs)
+        ss = sum(h * h for h in hs)
+        var = (ss - s * s / cnt) / (cnt - 1) if cnt >= 2 else (ss - s * s / cnt) / cnt
+        std = math.sqrt(var) if var > 0 else 0.0
+        if std > 0:
+            out[i] = (Z[i, 2] - s / cnt) / std
+    return out
+
+
+def fcluster_inconsistent(Z, t):
+    """scipy.cluster.hierarchy.fcluster(Z, t) (criterion 'inconsistent', depth 2): a node whose
+    whole sub-tree has inconsistency <= t becomes one flat cluster; clusters are numbered 1..
+    in left-first depth-first order."""
+    n = Z.shape[0] + 1
+    inc = inconsistency(Z, 2)
+    mx = np.zeros(n - 1)
+    for i in range(n - 1):  # children have smaller indices than their parent
+        m = inc[i]
+        for ch in (int(Z[i, 0]), int(Z[i, 1])):
+            if ch >= n:
+                m = max(m, mx[ch - n])
+        mx[i] = m
+    T = np.zeros(n, dtype=np.int64)
+    ncl = 0
+
+    def visit(node, leader):
+        nonlocal ncl
+        if not leader and mx[node] <= t:
+            leader = True
+            ncl += 1
+        for ch in (int(Z[node, 0]), int(Z[node, 1])):
+            if ch >= n:
+                visit(ch - n, leader)
+        for ch in (int(Z[node, 0]), int(Z[node, 1])):
+            if ch < n:
+                if not leader:
+                    ncl += 1
+                T[ch] = ncl
+    visit(n - 2, False)
+    return T
+
+
+def cluster_first_scan(state, mapa, obs):
+    """`Mapa.actualizar` with Lact == 0 (reference scripts/ICM_SLAM_tools.py:160-165): flat
+    clusters of the first scan, their means and sizes."""
+    if obs.shape[0] == 1:
+        c = np.zeros(1, dtype=np.int64)  # SciPy refuses a single observation; one cluster
+    else:
+        c = fcluster_inconsistent(single_linkage(obs), state.dist_thr) - 1
+    lact = int(c.max()) + 1
+    for i in range(lact):
+        mapa[:, i] = np.mean(obs[c == i, :], axis=0).T
+        state.cant_obs_i[i] = np.sum(c == i)
+    state.landmarks_actuales = lact
+    return mapa, c
+
+
+def init_pass(cfg, scans, u, odo, kept=None):
+    """The causal first pass that builds the initial poses and map (reference
+    `inicializar_online` + `inicializar_online_process`, scripts/ICM_ROS.py:57-119, on recorded
+    data: scan 0 seeds the map, then predict with g, associate against the RUNNING map,
+    one-sided solve).  Returns (x_init (3,T), map_init (2,K), state, labels of scan 0)."""
+    T = odo.shape[1]
+    if kept is None:
+        kept = prefilter_all(scans, cfg)
+    x0 = odo[:, 0].copy()
+    xt = x0.reshape((3, 1)).copy()
+    x = np.zeros((3, T))
+    x[:, 0] = x0
+    y = np.zeros((2, cfg.L))
+    state = MapState(cfg)
+    w0 = project_beams(x0, kept[0][:, 2:4])
+    y, c0 = cluster_first_scan(state, y, w0)
+    for t in range(1, T):
+        xtc = g(cfg, xt, u[:, t - 1])
+        if kept[t].shape[0] == 0:
+            xt = xtc + 0.0
+        else:
+            w = project_beams(xtc.reshape(3), kept[t][:, 2:4])
+            y, c = actualizar(state, y, y, w)
+            x_ant = xt.copy()
+            tg = y[:, c].T.copy()
+            xs = nelder_mead(lambda v: fun_x(cfg, v, x_ant, u, odo, t, kept[t][:, 0:2], tg), g(cfg, x_ant, u[:, t - 1]))
+            xt = xs.reshape((3, 1))
+        x[:, t] = xt.reshape(3)
+    y_raw, cnt_raw, lact_raw = y.copy(), state.cant_obs_i.copy(), state.landmarks_actuales
+    yy = filtrar(state, y)
+    return x, yy[:, :state.landmarks_actuales].copy(), state, c0, (y_raw, cnt_raw, lact_raw)

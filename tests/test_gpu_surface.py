@@ -99,3 +99,39 @@ def test_errors_match_reference_types(icm):
     m2.set_initial_state(init["x_init"], init["map_init"])
     with pytest.raises(ValueError):
         m2.iterations_process_offline(init["map_init"].copy(), init["x_init"].copy())
+
+
+def test_init_pass_matches_reference():
+    """BASELINE configs[0] end to end: raw data -> initialisation pass -> N sweeps, all through
+    the reference's class surface, against the reference's own init state and sweeps."""
+    from ICM_ROS import ICM_ROS
+    from ICM_SLAM_tools import ConfigICM
+    m = ICM_ROS(ConfigICM("config_default.yaml"))
+    m.load_data(os.path.join(GOLD, "data_IJAC2018.npz"))
+    m.inicializar_offline()
+    g = gold("init_pass.npz")
+    assert m.mapa_viejo.shape == g["map_init"].shape
+    assert np.abs(m.mapa_viejo - g["map_init"]).max() <= 1e-9
+    d = np.abs(m.positions - g["x_init"]).max(axis=0)
+    print("init pass vs reference: max|dx| %.3e, poses above 1e-9: %d" % (d.max(), int((d > 1e-9).sum())))
+    assert d.max() <= 5e-3 and (d > 1e-9).sum() <= 18
+    assert np.array_equal(m.mapa_obj.cant_obs_i, g["cant_obs_i"])
+    mapa_viejo, x = copy(m.mapa_viejo), copy(m.positions)
+    for it in range(m.config.N):
+        mapa_refinado, x = m.iterations_process_offline(mapa_viejo, x)
+        mapa_viejo = copy(mapa_refinado)
+    g2 = gold("sweep02.npz")
+    assert np.abs(mapa_viejo - g2["mapa"]).max() <= 1e-4
+    assert np.abs(x - g2["x"]).max() <= 5e-3
+
+
+def test_cluster_first_scan_matches_scipy():
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from scipy.spatial.distance import pdist
+    from icmslam_hip import cluster_first_scan
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        pts = np.concatenate([rng.normal(c, 0.15, (rng.integers(1, 7), 2)) for c in rng.uniform(-6, 6, (rng.integers(1, 6), 2))])
+        if pts.shape[0] < 2:
+            continue
+        assert np.array_equal(cluster_first_scan(pts, 1.0), fcluster(linkage(pdist(pts)), 1.0) - 1)

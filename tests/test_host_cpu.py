@@ -122,3 +122,19 @@ def test_synthetic_workload_is_deterministic_and_shardable():
     assert np.array_equal(lo.map_init, hi.map_init) and np.array_equal(lo.x_init, a.x_init)
     hits = (a.scans < 10.0).sum(axis=1)
     assert hits.mean() > 10 and a.scans.min() > 0
+
+
+def test_host_first_scan_clustering_equals_scipy():
+    """icm_cluster_first_scan (host C++) == fcluster(linkage(pdist(.)), t) - 1."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from scipy.spatial.distance import pdist
+    from icmslam_hip import cluster_first_scan
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        pts = np.concatenate([rng.normal(c, 0.2, (rng.integers(1, 8), 2)) for c in rng.uniform(-6, 6, (rng.integers(1, 6), 2))])
+        if pts.shape[0] < 2:
+            continue
+        assert np.array_equal(cluster_first_scan(pts, 1.0), fcluster(linkage(pdist(pts)), 1.0) - 1)
+    assert np.array_equal(cluster_first_scan(np.array([[1.0, 2.0]]), 1.0), [0])
+    s = gold("init_pass.npz")
+    assert set(s["labels_scan0"]) == {0, 1}

@@ -112,3 +112,29 @@ def test_redblack_differs_but_stays_close(cfg, kept):
     assert np.array_equal(out["sequential"][0], out["redblack"][0])
     d = np.abs(out["sequential"][1] - out["redblack"][1]).max()
     assert 0 < d < 0.1
+
+
+def test_init_pass_bitwise(cfg, kept):
+    """The causal initialisation pass (reference scripts/ICM_ROS.py:57-119 incl. the first-scan
+    clustering branch of Mapa.actualizar) against the reference's own result."""
+    zz, odo, u = dataset()
+    g = gold("init_pass.npz")
+    x, m, st, c0, raw = o.init_pass(cfg, zz, u, odo, kept=kept)
+    assert np.array_equal(c0, g["labels_scan0"])
+    assert np.array_equal(x, g["x_init"]) and np.array_equal(m, g["map_init"])
+    assert np.array_equal(st.cant_obs_i, g["cant_obs_i"]) and raw[2] == int(g["landmarks_raw"])
+    assert np.array_equal(raw[0], g["y_raw"]) and np.array_equal(raw[1], g["cant_obs_raw"])
+
+
+def test_clustering_restatement_equals_scipy():
+    from scipy.cluster.hierarchy import fcluster, inconsistent, linkage
+    from scipy.spatial.distance import pdist
+    rng = np.random.default_rng(11)
+    for _ in range(150):
+        pts = np.concatenate([rng.normal(c, 0.15, (rng.integers(1, 6), 2)) for c in rng.uniform(-6, 6, (rng.integers(1, 6), 2))])
+        if pts.shape[0] < 2:
+            continue
+        Z, Zs = o.single_linkage(pts), linkage(pdist(pts))
+        assert np.array_equal(Z, Zs)
+        assert np.array_equal(o.inconsistency(Z, 2), inconsistent(Zs, 2)[:, 3])
+        assert np.array_equal(o.fcluster_inconsistent(Z, 1.0), fcluster(Zs, 1.0))
