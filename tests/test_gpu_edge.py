@@ -1,0 +1,189 @@
+"""Edge cases and size-independent properties of the HIP sweep."""
+import numpy as np
+import pytest
+
+from util import Cfg, dataset, gold
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_redblack(cfg, zz, odo, u, x_init, map_init, lact, T):
+    from oracle import icm_oracle as o
+    ocfg = o.OracleConfig.from_config(cfg)
+    st = o.MapState(ocfg, lact)
+    x = np.ascontiguousarray(x_init[:, :T]).copy()
+    m, x = o.sweep(ocfg, st, zz[:, :T], u[:, :T], odo[:, :T], odo[:, 0], map_init.copy(), x, schedule="redblack")
+    return m, x, st
+
+
+@pytest.mark.parametrize("form", ["moments", "beam", "entry"])
+def test_anisotropic_weights_match_oracle(form):
+    """Q, R not multiples of the identity and cte_odom != 1: exercises the theta-dependent
+    scatter term of the grouped energy forms and every weight of the priors."""
+    from icmslam_hip import SweepEngine
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    T = 300
+    cfg = Cfg(cota=20.0, Q=np.diag([2.0, 0.5]), R=np.diag([1.5, 0.7, 2.0]), cte_odom=0.3)
+    eng = SweepEngine(cfg)
+    eng.upload(zz[:, :T], odo[:, :T], u[:, :T])
+    eng.set_energy_form(form)
+    x = np.ascontiguousarray(init["x_init"][:, :T]).copy()
+    mo, co, K = eng.sweep(init["map_init"], x, odo[:, 0], int(init["landmarks_actuales"]), "redblack")
+    eng.close()
+    mref, xref, st = _oracle_redblack(cfg, zz, odo, u, init["x_init"], init["map_init"], int(init["landmarks_actuales"]), T)
+    d = np.abs(x - xref).max(axis=0)
+    print("anisotropic (%s): max|dx| %.3e, poses above 1e-9: %d" % (form, d.max(), int((d > 1e-9).sum())))
+    assert K == mref.shape[1] and np.abs(mo[:, :K] - mref).max() <= 1e-9
+    assert d.max() <= 5e-3 and (d > 1e-9).sum() <= 3
+
+
+def test_first_scan_without_beams_returns_inputs():
+    """reference scripts/ICM_ROS.py:133-135."""
+    from icmslam_hip import SweepEngine
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    T = 60
+    z2 = zz[:, :T].copy()
+    z2[:, 0] = 10.0  # nothing in range in scan 0
+    eng = SweepEngine(Cfg(cota=5.0))
+    eng.upload(z2, odo[:, :T], u[:, :T])
+    x = np.ascontiguousarray(init["x_init"][:, :T]).copy()
+    x_before = x.copy()
+    assert eng.sweep(init["map_init"], x, odo[:, 0], 11, "sequential") is None
+    assert np.array_equal(x, x_before)
+    eng.close()
+
+
+def test_last_pose_without_beams_raises_index_error():
+    """reference scripts/ICM_ROS.py:144 indexes x[:, T]."""
+    from icmslam_hip import SweepEngine
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    T = 60
+    z2 = zz[:, :T].copy()
+    z2[:, -1] = 10.0
+    eng = SweepEngine(Cfg(cota=5.0))
+    eng.upload(z2, odo[:, :T], u[:, :T])
+    x = np.ascontiguousarray(init["x_init"][:, :T]).copy()
+    for sch in ("sequential", "redblack"):
+        with pytest.raises(IndexError):
+            eng.sweep(init["map_init"], x, odo[:, 0], 11, sch)
+    eng.close()
+
+
+def test_single_beam_scans_and_ragged_counts():
+    """Scans with 0, 2, few and many kept beams in one sequence; the pre-filter's '<= 1 beam
+    in range -> empty' rule (scripts/ICM_SLAM_tools.py:41,55)."""
+    from icmslam_hip import SweepEngine
+    from oracle import icm_oracle as o
+    zz, odo, u = dataset()
+    T = 40
+    z2 = zz[:, :T].copy()
+    z2[:, 5] = 10.0
+    z2[:, 6] = 10.0
+    z2[90, 6] = 3.0          # one beam only (median filter removes it anyway)
+    z2[:, 7] = 10.0
+    z2[60:63, 7] = 4.0       # three adjacent beams -> median keeps some
+    eng = SweepEngine(Cfg())
+    eng.upload(z2, odo[:, :T], u[:, :T])
+    off, bk, d, bx, by = eng.kept_beams()
+    eng.close()
+    kept = o.prefilter_all(z2, o.OracleConfig())
+    for t in range(T):
+        ref = kept[t] if kept[t].ndim == 2 else np.zeros((0, 4))
+        assert off[t + 1] - off[t] == ref.shape[0]
+        assert np.array_equal(d[off[t]:off[t + 1]], ref[:, 0]) and np.array_equal(bx[off[t]:off[t + 1]], ref[:, 2])
+    assert off[6] == off[5] and off[7] == off[6]
+
+
+def test_brute_force_equals_grid_at_s1_size():
+    """Association labels of the grid search vs the literal all-landmarks search on the S1
+    workload (10k poses, 1k landmarks): identical labels, hence identical sweeps."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import WORKLOADS, make_workload
+    wl = make_workload(*WORKLOADS["S1"])
+    eng = SweepEngine(ConfigICM(D=wl.config))
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    eng.set_debug(True)
+    out = []
+    for brute in (False, True):
+        eng.set_brute_force(brute)
+        eng.set_state(wl.map_init, wl.x_init, wl.x0)
+        eng.sweep_device("redblack")
+        out.append((eng.association()[0].copy(),) + eng.get_state())
+    eng.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert np.array_equal(a, b)
+    assert (out[0][0] >= 0).all()
+
+
+def test_s2_full_size_properties():
+    """BASELINE configs[3] at full size (100k poses / 10k landmarks / 720 beams): the sweep is
+    deterministic (two runs bit-equal), the sharded phase path equals the unsharded one, every
+    kept beam gets a label below landmarks_actuales, the counters sum to the kept beams, and
+    the map change between sweeps (calc_cambio) shrinks."""
+    import torch
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import NoComm, ShardedSweep, partition, run_virtual_ranks
+    from icmslam_hip.synthetic import WORKLOADS, make_workload
+    wl = make_workload(*WORKLOADS["S2"])
+    cfg = ConfigICM(D=wl.config)
+    eng = SweepEngine(cfg)
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    runs, cambio = [], []
+    for rep in range(2):
+        eng.set_state(wl.map_init, wl.x_init, wl.x0)
+        prev = wl.map_init
+        for _ in range(5):
+            eng.sweep_device("redblack")
+            if rep == 0:  # the reference's convergence metric (calc_cambio, scripts/ICM_SLAM_tools.py:490-495)
+                _, mm, _, kk = eng.get_state()
+                cur = mm[:, :kk]
+                dd = np.sqrt(((cur[:, :, None] - prev[:, None, :]) ** 2).sum(axis=0)).min(axis=1)
+                cambio.append(float(dd.mean()))
+                prev = cur.copy()
+        runs.append(eng.get_state())
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)
+    x, m, c, K = runs[0]
+    yr, cr, la = eng.raw_map()
+    st = eng.last_stats()
+    assert cr[:la].sum() == st["kept_beams"] == eng.nnz
+    eng.set_debug(True)
+    eng.sweep_device("redblack")
+    lab = eng.association()[0]
+    assert lab.min() >= 0 and lab.max() < eng.raw_map()[2]
+    eng.close()
+    print("S2 mean landmark change per sweep:", ["%.2e" % v for v in cambio], "landmarks", K)
+    assert cambio[-1] < 0.5 * cambio[0]
+    # sharded (2 virtual ranks, shared buffers) == unsharded, 2 sweeps
+    world = 2
+    _, parts = partition(wl.T, world)
+    engines, buffers = [], None
+    for r, (a, b) in enumerate(parts):
+        e = SweepEngine(cfg)
+        e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
+        run = ShardedSweep(e, r, world, wl.T, comm=NoComm(), buffers=buffers)
+        buffers = (run.stats, run.poses)
+        run.set_state(wl.map_init, wl.x_init, wl.x0)
+        engines.append(e)
+    run_virtual_ranks(engines, 2)
+    torch.cuda.synchronize()
+    xs, ms, cs, Ks = engines[0].get_state()
+    for e in engines:
+        e.close()
+    e1 = SweepEngine(cfg)
+    e1.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    e1.set_state(wl.map_init, wl.x_init, wl.x0)
+    for _ in range(2):
+        e1.sweep_device("redblack")
+    x1, m1, c1, K1 = e1.get_state()
+    e1.close()
+    assert Ks == K1 and np.abs(ms - m1).max() <= 1e-9 and np.array_equal(cs, c1)
+    d = np.abs(xs - x1).max(axis=0)
+    print("S2 sharded x2 vs unsharded: max|dx| %.3e, poses above 1e-9: %d" % (d.max(), int((d > 1e-9).sum())))
+    assert d.max() <= 5e-3 and (d > 1e-9).sum() <= 100
