@@ -209,7 +209,8 @@ __device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const P
         cth = m.co + (m.co * al - m.so * be);
         sth = m.so + (m.so * al + m.co * be);
     } else {
-        sincos(th, &sth, &cth);
+        sth = sin(th);
+        cth = cos(th);
         be = sth * m.co - cth * m.so;                 // sin(th - th_o)
         const double cd = cth * m.co + sth * m.so;    // cos(th - th_o)
         const double den = 1.0 + cd;

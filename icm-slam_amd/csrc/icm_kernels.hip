@@ -822,6 +822,7 @@ struct FiltrarArgs {
     int* g_cell;
     LmRec* g_lm;
     int* info;
+    unsigned long long* stamps;  // optional phase time stamps (100 MHz), diagnostics only
 };
 
 __device__ __forceinline__ int block_exscan_1024(int v, int* wsum, int& total) {
@@ -944,6 +945,8 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
     __shared__ int s_cnt[2];
     __shared__ GridParams s_gp;
     const int tid = threadIdx.x;
+#define FSTAMP(i) do { if (a.stamps && tid == 0) a.stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    FSTAMP(0);
     // landmarks in use before the filter: lact0 + the new ones of all ranks
     int lact = a.lact0 + a.n_new_loc;
     if (a.world > 1) {
@@ -971,19 +974,23 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
         s_cnt[1] = 0;
     }
     __syncthreads();
-    // 2. nearest other survivor (only those closer than dist_thr matter)
-    if (n > 1) {
-        // a coarse grid (4 x the gate) is enough for the pair check and keeps the cell arrays small
-        block_build_grid(a.px, a.py, n, 4.0 * a.thr * (1.0 + 1e-9), a.max_cells, a.cid, a.cell_cnt, a.cell_fill, a.tbl, &s_gp, red, wsum);
+    FSTAMP(1);
+    // 2. ONE fine grid (cell >= dist_thr) over the survivors, written straight into the search
+    //    structures of the next sweep, and the pair check on it: is any other survivor closer
+    //    than dist_thr, or coincident?
+    int merges = 0, coincident = 0;
+    if (n > 0) {
+        block_build_grid(a.px, a.py, n, a.thr * (1.0 + 1e-9), a.max_cells, a.cid, a.g_cell, a.cell_fill, a.g_lm, &s_gp, red, wsum);
         const GridParams gp = s_gp;
+        FSTAMP(2);
         for (int i = tid; i < n; i += kFB) {
             const double xi = a.px[i], yi = a.py[i];
             const int cx = grid_cell(xi, gp.gx0, gp.inv, gp.nx), cy = grid_cell(yi, gp.gy0, gp.inv, gp.ny);
             const int c0 = max(cx - 1, 0), c1 = min(cx + 1, gp.nx - 1);
             bool close = false, same = false;
             for (int ry = max(cy - 1, 0); ry <= min(cy + 1, gp.ny - 1); ++ry)
-                for (int p = a.cell_cnt[ry * gp.nx + c0]; p < a.cell_cnt[ry * gp.nx + c1 + 1]; ++p) {
-                    const LmRec c = a.tbl[p];
+                for (int p = a.g_cell[ry * gp.nx + c0]; p < a.g_cell[ry * gp.nx + c1 + 1]; ++p) {
+                    const LmRec c = a.g_lm[p];
                     if (c.id == i) continue;
                     const double dx = xi - c.x, dy = yi - c.y;
                     const double d = sqrt(dx * dx + dy * dy);
@@ -994,16 +1001,21 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
             if (same) atomicAdd(&s_cnt[1], 1);
         }
         __syncthreads();
+        merges = s_cnt[0];
+        coincident = s_cnt[1];
     }
-    const int merges = s_cnt[0], coincident = s_cnt[1];
+    FSTAMP(3);
     const bool host = n == 0 || merges > 0 || coincident > 0;
     if (tid == 0) {
         a.info[0] = n;
         a.info[1] = host ? 1 : 0;
         a.info[2] = merges;
     }
-    if (host) return;
-    // 3. refined map = survivors; count-weighted mean of a single term is (y*n)/n (:258-260)
+    if (host) return;  // (the search structures hold the raw survivors: the host path re-uploads them)
+    // 3. refined map = survivors; the count-weighted mean of a single term is (y*n)/n (:258-260).
+    //    The grid cells were assigned from the raw coordinates, which differ from the refined
+    //    ones by an ulp at most -- far inside the 1e-9 slack of the cell edge over dist_thr --
+    //    so only the table's coordinates are rewritten.
     for (int i = tid; i < a.L; i += kFB) {
         if (i < n) {
             const double c = a.pc[i];
@@ -1015,7 +1027,14 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
         }
     }
     __syncthreads();
-    block_build_grid(a.mapx, a.mapy, n, a.thr * (1.0 + 1e-9), a.max_cells, a.cid, a.g_cell, a.cell_fill, a.g_lm, a.gpar, red, wsum);
+    for (int p = tid; p < n; p += kFB) {
+        const int id = a.g_lm[p].id;
+        a.g_lm[p].x = a.mapx[id];
+        a.g_lm[p].y = a.mapy[id];
+    }
+    if (tid == 0) *a.gpar = s_gp;
+    FSTAMP(5);
+#undef FSTAMP
 }
 
 // Target per kept beam: y[:, c] of scripts/ICM_ROS.py:152 (parity tests, per-beam energy).
@@ -1191,7 +1210,8 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
     // expansion point = this pose's previous-sweep value (still in x: nobody else writes it)
     m.pox = a.x[3 * (size_t)tg]; m.poy = a.x[3 * (size_t)tg + 1];
     m.tho = a.x[3 * (size_t)tg + 2];
-    sincos(m.tho, &m.so, &m.co);
+    m.so = sin(m.tho);  // (no sincos(&member): an address-taken struct member forces scratch)
+    m.co = cos(m.tho);
     double sx, sy, st;
     if (!last) {
         sx = (prev[0] + xp[0]) / 2.0; sy = (prev[1] + xp[1]) / 2.0; st = (prev[2] + xp[2]) / 2.0;
