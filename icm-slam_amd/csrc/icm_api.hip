@@ -570,7 +570,11 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     a.tgt = h->tgt.p; a.pose_c = h->pose_c.p; a.pose_m = h->pose_m.p;
     a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
     a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
-    a.diag = h->diag.p;
+    if (h->debug && !h->diag.p) {
+        HIPCHK(h, h->diag.reserve(3 * (size_t)h->T));
+        HIPCHK(h, hipMemsetAsync(h->diag.p, 0, 3 * (size_t)h->T * sizeof(double), h->stream));
+    }
+    a.diag = h->debug ? h->diag.p : nullptr;
     if (schedule == ICM_SCHEDULE_SEQUENTIAL) {
         if (h->world != 1) FAIL(h, ICM_ERR_UNSUPPORTED, "the sequential (reference-order) schedule is one dependent chain and cannot be sharded");
         if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
@@ -910,6 +914,15 @@ int icm_last_stats(const icm_handle* h, int64_t* out4) {
 int icm_set_debug(icm_handle* h, int on) {
     if (!h) return ICM_ERR_ARG;
     h->debug = on != 0;
+    return ICM_OK;
+}
+
+int icm_get_solve_diag(icm_handle* h, double* out) {
+    if (!h || !out) return ICM_ERR_ARG;
+    if (!h->diag.p) FAIL(h, ICM_ERR_ARG, "icm_get_solve_diag: enable icm_set_debug before the sweep");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->diag.p, 3 * (size_t)h->T * sizeof(double), hipMemcpyDeviceToHost));
     return ICM_OK;
 }
 

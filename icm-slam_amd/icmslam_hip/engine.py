@@ -321,6 +321,12 @@ class SweepEngine:
         """Keep per-beam labels / targets of the next sweeps (for `association()`)."""
         self._chk(self.lib.icm_set_debug(self.h, int(bool(on))))
 
+    def solve_diag(self):
+        """(T,3) [final energy, NM iterations, function evaluations] per pose (debug on)."""
+        out = np.zeros((self.T, 3))
+        self._chk(self.lib.icm_get_solve_diag(self.h, dptr(out)))
+        return out
+
     def set_energy_form(self, form):
         """0 / 'moments' (default), 1 / 'beam' (literal per-beam sum), 2 / 'entry'."""
         form = {"moments": 0, "beam": 1, "entry": 2}.get(form, form)

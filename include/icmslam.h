@@ -170,6 +170,9 @@ int icm_set_brute_force(icm_handle *h, int on);
 /* Keep the per-beam outputs of a sweep (label and running-mean target of every kept beam)
  * for icm_get_association; off by default (they cost 28 B of HBM traffic per kept beam). */
 int icm_set_debug(icm_handle *h, int on);
+/* With debug on: per pose (T,3) row-major [final energy, NM iterations, function evaluations]
+ * of the last sweep's solve (0 for poses without a solve). */
+int icm_get_solve_diag(icm_handle *h, double *out);
 /* Form in which the pose solves evaluate the observation energy h(x) of
  * scripts/ICM_ROS.py:171-200 -- the same function in three algebraically identical forms:
  *   0 (default) moment form: quadratic form in (dp, cos d - 1, sin d) about the pose's

@@ -187,3 +187,34 @@ def test_s2_full_size_properties():
     d = np.abs(xs - x1).max(axis=0)
     print("S2 sharded x2 vs unsharded: max|dx| %.3e, poses above 1e-9: %d" % (d.max(), int((d > 1e-9).sum())))
     assert d.max() <= 5e-3 and (d > 1e-9).sum() <= 100
+
+
+def test_landmark_merge_path_matches_oracle():
+    """Two map landmarks 0.4 m apart (< dist_thr) split the beams of one trunk; Mapa.filtrar must
+    merge them (count-weighted mean, label propagation, renumbering).  The fused GPU filter
+    detects the close pair and hands over to the exact host routine; result vs the oracle."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    from oracle import icm_oracle as o
+    wl = make_workload(500, 49, 180)
+    cfg = ConfigICM(D=dict(wl.config, cota=3.0))
+    # duplicate the three landmarks nearest to the start of the path, shifted by 0.4 m
+    d0 = np.hypot(*(wl.map_init - wl.x_true[:2, [0]]))
+    near = np.argsort(d0)[:3]
+    extra = wl.map_init[:, near] + np.array([[0.4], [0.0]])
+    map0 = np.concatenate((wl.map_init, extra), axis=1)
+    eng = SweepEngine(cfg)
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    x = wl.x_init.copy()
+    mo, co, K = eng.sweep(map0, x, wl.x0, map0.shape[1], "redblack")
+    yr, cr, la = eng.raw_map()
+    eng.close()
+    ocfg = o.OracleConfig.from_config(cfg)
+    st = o.MapState(ocfg, map0.shape[1])
+    xo = wl.x_init.copy()
+    mref, xo = o.sweep(ocfg, st, wl.scans.T, wl.u, wl.odometry, wl.x0, map0.copy(), xo, schedule="redblack")
+    # the duplicates really were in play and really were merged away
+    assert (cr[49:52] > 0).all() and K == mref.shape[1] and K < (cr[:la] >= 3.0).sum()
+    assert np.abs(mo[:, :K] - mref).max() <= 1e-9 and np.array_equal(co, st.cant_obs_i)
+    assert np.abs(x - xo).max() <= 1e-9
