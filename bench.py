@@ -68,14 +68,14 @@ def survey_bytes_per_pose(B, Kt, K, T):
 
 
 def cpu_baseline(wl, cfg, n_pose, schedule):
-    """The NumPy oracle (reference restatement, one core) on the first n_pose poses of the
-    same workload at full landmark count."""
+    """The NumPy oracle (the reference's own arithmetic, library for library) on one core, on
+    the first n_pose poses of the same workload at the full landmark count."""
     from oracle import icm_oracle as o
     ocfg = o.OracleConfig.from_config(cfg)
     scans = np.ascontiguousarray(wl.scans[:n_pose].T)
     u, odo = wl.u[:, :n_pose], wl.odometry[:, :n_pose]
     st = o.MapState(ocfg, wl.K)
-    x = np.ascontiguousarray(wl.x_init[:, :n_pose])
+    x = np.ascontiguousarray(wl.x_init[:, :n_pose]).copy()
     t0 = time.perf_counter()
     kept = o.prefilter_all(scans, ocfg)
     t1 = time.perf_counter()
@@ -85,6 +85,24 @@ def cpu_baseline(wl, cfg, n_pose, schedule):
         pass  # a short prefix may leave no landmark above `cota`; the sweep work is done by then
     t2 = time.perf_counter()
     return (n_pose - 1) / (t2 - t1), t1 - t0
+
+
+def cpu_baseline_c(wl, cfg, n_pose, schedule):
+    """The compiled C restatement of the same algorithm (oracle/icm_oracle_c.c, gcc -O2, one
+    core): brute-force association, per-beam energy, SciPy's Nelder-Mead -- what the reference's
+    sweep costs without the Python interpreter."""
+    from oracle import c_oracle as co
+    scans = np.ascontiguousarray(wl.scans[:n_pose].T)
+    u, odo = np.ascontiguousarray(wl.u[:, :n_pose]), np.ascontiguousarray(wl.odometry[:, :n_pose])
+    kept = co.prefilter(cfg, scans)
+    x = np.ascontiguousarray(wl.x_init[:, :n_pose]).copy()
+    t1 = time.perf_counter()
+    try:
+        co.sweep(cfg, kept, u, odo, wl.x0, wl.map_init, x, wl.K, schedule)
+    except ValueError:
+        pass
+    t2 = time.perf_counter()
+    return (n_pose - 1) / (t2 - t1)
 
 
 def main():
@@ -218,13 +236,19 @@ def main():
     if roof is not None:
         out["roofline"] = roof
     if rank == 0 and world == 1 and args.cpu_poses != 0:
-        n_cpu = args.cpu_poses if args.cpu_poses > 0 else {"S2": 400, "S1": 1500}.get(args.workload, T)
-        n_cpu = min(n_cpu, t_end)
-        v, tpre = cpu_baseline(wl, cfg, n_cpu, schedule)
-        out["cpu_baseline"] = {"value": round(v, 2), "unit": "pose-updates/s", "cores": 1, "kind": "port",
-                               "sample": "NumPy oracle (oracle/icm_oracle.py), one red-black sweep over the first %d poses of "
-                                         "the same sequence at the full %d-landmark map; host has %d cores" % (n_cpu, K, os.cpu_count())}
-        out["gpu_over_cpu"] = round(value / v, 1)
+        n_c = args.cpu_poses if args.cpu_poses > 0 else {"S2": 2500, "S1": 10000}.get(args.workload, T)
+        n_c = min(n_c, t_end)
+        v_c = cpu_baseline_c(wl, cfg, n_c, schedule)
+        out["cpu_baseline"] = {"value": round(v_c, 1), "unit": "pose-updates/s", "cores": 1, "kind": "port",
+                               "sample": "compiled C oracle (oracle/icm_oracle_c.c, gcc -O2, one core; brute-force association "
+                                         "and per-beam energy like the reference), one red-black sweep over the first %d poses of "
+                                         "the same sequence at the full %d-landmark map; host has %d cores" % (n_c, K, os.cpu_count())}
+        n_py = min({"S2": 300, "S1": 1000}.get(args.workload, T), t_end)
+        v_py, _ = cpu_baseline(wl, cfg, n_py, schedule)
+        out["cpu_baseline_numpy"] = {"value": round(v_py, 2), "unit": "pose-updates/s", "cores": 1, "kind": "port",
+                                     "sample": "NumPy oracle (oracle/icm_oracle.py: the reference's arithmetic library for library, "
+                                               "interpreter included), first %d poses" % n_py}
+        out["gpu_over_cpu"] = {"vs_c_port": round(value / v_c, 1), "vs_numpy_port": round(value / v_py, 1)}
     if rank == 0:
         print(json.dumps(out))
     eng.close()

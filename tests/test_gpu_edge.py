@@ -218,3 +218,33 @@ def test_landmark_merge_path_matches_oracle():
     assert (cr[49:52] > 0).all() and K == mref.shape[1] and K < (cr[:la] >= 3.0).sum()
     assert np.abs(mo[:, :K] - mref).max() <= 1e-9 and np.array_equal(co, st.cant_obs_i)
     assert np.abs(x - xo).max() <= 1e-9
+
+
+def test_s1_full_size_against_c_oracle():
+    """BASELINE configs[2] workload at full size (10 000 poses / 1 000 landmarks / 360 beams), two
+    red-black sweeps: HIP vs the compiled C oracle (brute-force association, per-beam energy,
+    running-mean recurrence -- the reference's literal arithmetic)."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import WORKLOADS, make_workload
+    from oracle import c_oracle as co
+    wl = make_workload(*WORKLOADS["S1"])
+    cfg = ConfigICM(D=wl.config)
+    eng = SweepEngine(cfg)
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    off, bk, d, bx, by = eng.kept_beams()
+    keptc = co.prefilter(cfg, wl.scans.T)
+    assert np.array_equal(off, keptc[0]) and np.array_equal(bk, keptc[1]) and np.array_equal(bx, keptc[4])
+    x = wl.x_init.copy()
+    xc = wl.x_init.copy()
+    mv, la = wl.map_init, wl.K
+    mvc, lac = wl.map_init, wl.K
+    for it in range(2):
+        mo, cnt, K = eng.sweep(mv, x, wl.x0, la, "redblack")
+        mv, la = mo[:, :K].copy(), K
+        mvc, cntc, lac, raw = co.sweep(cfg, keptc, wl.u, wl.odometry, wl.x0, mvc, xc, lac, "redblack")
+        d_x = np.abs(x - xc).max(axis=0)
+        print("S1 sweep %d: K %d/%d  max|dmap| %.2e  max|dx| %.2e  poses above 1e-9: %d" % (it + 1, K, lac, np.abs(mv - mvc).max(), d_x.max(), int((d_x > 1e-9).sum())))
+        assert K == lac and np.array_equal(cnt, cntc) and np.abs(mv - mvc).max() <= 1e-9
+        assert d_x.max() <= 5e-3 and (d_x > 1e-9).sum() <= 10
+    eng.close()

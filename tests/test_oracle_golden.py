@@ -138,3 +138,44 @@ def test_clustering_restatement_equals_scipy():
         assert np.array_equal(Z, Zs)
         assert np.array_equal(o.inconsistency(Z, 2), inconsistent(Zs, 2)[:, 3])
         assert np.array_equal(o.fcluster_inconsistent(Z, 1.0), fcluster(Zs, 1.0))
+
+
+def test_c_oracle_matches_reference_goldens():
+    """oracle/icm_oracle_c.c (the compiled restatement) against the same goldens: pre-filter rows
+    bit-exact, the Appendix C solve, poses/map after sweeps 1 and 2 within 1e-9."""
+    from oracle import c_oracle as co
+    from util import Cfg
+    cfgc = Cfg()
+    zz, odo, u = dataset()
+    keptc = co.prefilter(cfgc, zz)
+    fz = gold("filtrar_z.npz")
+    assert np.array_equal(keptc[0], fz["offsets"])
+    for col, arr in ((0, keptc[2]), (1, keptc[3]), (2, keptc[4]), (3, keptc[5])):
+        assert np.array_equal(arr, fz["rows"][:, col])
+    s, init = gold("solve_t100.npz"), gold("init_pass.npz")
+    xi = init["x_init"]
+    out = co.solve_one(cfgc, 1, xi[:, 99], xi[:, 101], u[:, 99:101], odo[:, 99:102], s["beams"][:, 0:2], s["targets"])
+    assert np.abs(out[:3] - s["xopt"]).max() <= 1e-12 and (out[4], out[5]) == (26, 52)
+    x, mv, la = xi.copy(), init["map_init"].copy(), int(init["landmarks_actuales"])
+    for it in (1, 2):
+        mv, c, la, raw = co.sweep(cfgc, keptc, u, odo, odo[:, 0], mv, x, la, "sequential")
+        g = gold("sweep%02d.npz" % it)
+        assert la == int(g["landmarks_actuales"]) and np.array_equal(c, g["cant_obs_i"])
+        assert np.abs(x - g["x"]).max() <= 1e-9 and np.abs(mv - g["mapa"]).max() <= 1e-9
+
+
+def test_c_oracle_equals_numpy_oracle_redblack(cfg, kept):
+    from oracle import c_oracle as co
+    from util import Cfg
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    T = 200
+    cc = Cfg(cota=20.0)
+    keptc = co.prefilter(cc, zz[:, :T])
+    xc = np.ascontiguousarray(init["x_init"][:, :T]).copy()
+    mc, cntc, Kc, _ = co.sweep(cc, keptc, u[:, :T], odo[:, :T], odo[:, 0], init["map_init"], xc, 11, "redblack")
+    c2 = o.OracleConfig(cota=20.0)
+    st = o.MapState(c2, 11)
+    xn = np.ascontiguousarray(init["x_init"][:, :T]).copy()
+    mn, xn = o.sweep(c2, st, zz[:, :T], u[:, :T], odo[:, :T], odo[:, 0], init["map_init"].copy(), xn, schedule="redblack", kept=kept[:T])
+    assert Kc == mn.shape[1] and np.abs(mc - mn).max() <= 1e-12 and np.abs(xc - xn).max() <= 1e-9
