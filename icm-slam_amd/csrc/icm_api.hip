@@ -2,8 +2,6 @@
 // orchestration.  All device work goes to one HIP stream; the only host round trips per
 // sweep are two small counter reads (entry / new-landmark counts) and the raw-map download
 // for the host-side Mapa.filtrar.
-#include <cstdio>
-#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -540,7 +538,6 @@ int icm_sweep_targets(icm_handle* h) {
         fa.cell_cnt = h->fl_cell_cnt.p; fa.cell_fill = h->fl_cell_fill.p; fa.tbl = h->fl_tbl.p;
         fa.mapx = h->mapx.p; fa.mapy = h->mapy.p; fa.counts_new = h->counts_new.p;
         fa.gpar = h->gpar.p; fa.g_cell = h->g_cell.p; fa.g_lm = h->g_lm.p; fa.info = h->fl_info.p;
-        fa.stamps = getenv("ICM_FILTRAR_STAMPS") ? reinterpret_cast<unsigned long long*>(h->fl_cell_fill.p + 8 * (size_t)L + 4000) : nullptr;
         if (h->timing) {  // serialised on the main stream so that the events bracket it
             TIMED(h, KID_FILTRAR, (k_filtrar_grid<<<1, kFB, 0, h->stream>>>(fa)));
             HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
@@ -590,13 +587,7 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
                 // 64 poses per wavefront.  (Measured: spreading a colour over more, partly filled
                 // waves never helps -- the launch lasts as long as its slowest pose's chain of
                 // Nelder-Mead iterations, and extra waves only add issue pressure.)
-                int lpw = 64, wpe = 1;
-                if (const char* ev = getenv("ICM_SOLVE_VARIANT")) sscanf(ev, "%dx%d", &lpw, &wpe);  // experiment knob
-#define SOLVE_M(LPW, WPE) TIMED(h, KID_SOLVE, (k_solve_m_colour<LPW, WPE><<<nblocks_waves((nw + LPW - 1) / LPW), kBlock, 0, h->stream>>>(a, col)))
-#define SOLVE_W(LPW) do { if (wpe >= 4) SOLVE_M(LPW, 4); else if (wpe >= 2) SOLVE_M(LPW, 2); else SOLVE_M(LPW, 1); } while (0)
-                if (lpw <= 8) SOLVE_W(8); else if (lpw <= 16) SOLVE_W(16); else if (lpw <= 32) SOLVE_W(32); else SOLVE_W(64);
-#undef SOLVE_W
-#undef SOLVE_M
+                TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_waves((nw + kWave - 1) / kWave), kBlock, 0, h->stream>>>(a, col)));
             }
         }
     } else {
@@ -629,12 +620,6 @@ int icm_sweep_finish(icm_handle* h) {
     if (h->lact_raw > (int64_t)L) FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L");
     h->h_yraw.assign(h->pin_d, h->pin_d + 2 * L);
     h->h_cntraw.assign(h->pin_d + 2 * L, h->pin_d + 3 * L);
-    if (getenv("ICM_FILTRAR_STAMPS") && h->gpu_filtrar) {
-        unsigned long long st[6];
-        (void)hipMemcpy(st, h->fl_cell_fill.p + 8 * L + 4000, sizeof(st), hipMemcpyDeviceToHost);
-        fprintf(stderr, "filtrar phases [us]: prune %.1f grid %.1f pairs %.1f refine %.1f\n", (st[1] - st[0]) / 100.0,
-                (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0, (st[5] - st[3]) / 100.0);
-    }
     if (h->gpu_filtrar && h->pin_i[9] == 0) {
         // Mapa.filtrar and the search grid of the refined map were produced on the GPU
         // (k_filtrar_grid); the refined map becomes the next mapa_viejo (scripts/ICM_ROS.py:311)

@@ -822,7 +822,6 @@ struct FiltrarArgs {
     int* g_cell;
     LmRec* g_lm;
     int* info;
-    unsigned long long* stamps;  // optional phase time stamps (100 MHz), diagnostics only
 };
 
 __device__ __forceinline__ int block_exscan_1024(int v, int* wsum, int& total) {
@@ -945,8 +944,6 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
     __shared__ int s_cnt[2];
     __shared__ GridParams s_gp;
     const int tid = threadIdx.x;
-#define FSTAMP(i) do { if (a.stamps && tid == 0) a.stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    FSTAMP(0);
     // landmarks in use before the filter: lact0 + the new ones of all ranks
     int lact = a.lact0 + a.n_new_loc;
     if (a.world > 1) {
@@ -974,7 +971,6 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
         s_cnt[1] = 0;
     }
     __syncthreads();
-    FSTAMP(1);
     // 2. ONE fine grid (cell >= dist_thr) over the survivors, written straight into the search
     //    structures of the next sweep, and the pair check on it: is any other survivor closer
     //    than dist_thr, or coincident?
@@ -982,7 +978,6 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
     if (n > 0) {
         block_build_grid(a.px, a.py, n, a.thr * (1.0 + 1e-9), a.max_cells, a.cid, a.g_cell, a.cell_fill, a.g_lm, &s_gp, red, wsum);
         const GridParams gp = s_gp;
-        FSTAMP(2);
         for (int i = tid; i < n; i += kFB) {
             const double xi = a.px[i], yi = a.py[i];
             const int cx = grid_cell(xi, gp.gx0, gp.inv, gp.nx), cy = grid_cell(yi, gp.gy0, gp.inv, gp.ny);
@@ -1004,7 +999,6 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
         merges = s_cnt[0];
         coincident = s_cnt[1];
     }
-    FSTAMP(3);
     const bool host = n == 0 || merges > 0 || coincident > 0;
     if (tid == 0) {
         a.info[0] = n;
@@ -1033,8 +1027,6 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
         a.g_lm[p].y = a.mapy[id];
     }
     if (tid == 0) *a.gpar = s_gp;
-    FSTAMP(5);
-#undef FSTAMP
 }
 
 // Target per kept beam: y[:, c] of scripts/ICM_ROS.py:152 (parity tests, per-beam energy).
@@ -1228,15 +1220,10 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
     }
 }
 
-// Red-black half sweep, moment form: one LANE per pose of the colour.  LPW = active lanes
-// per wavefront: the solves are latency-bound (~60-130 dependent energy evaluations per
-// pose), so for moderate pose counts it pays to spread the poses over more, partly filled
-// wavefronts (more waves in flight per SIMD, shorter max-over-lanes tail); WPE = waves per
-// SIMD the register allocation must allow.
-template <int LPW, int WPE>
-__global__ __launch_bounds__(kBlock, WPE) void k_solve_m_colour(SolveArgs a, int colour) {
+// Red-black half sweep, moment form: one LANE per pose of the colour (64 poses per wave).
+__global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colour) {
     const int lane = lane_id();
-    if (lane >= LPW) return;
+    constexpr int LPW = kWave;
     const int w = (blockIdx.x * kWavesPerBlock + wave_in_block()) * LPW + lane;
     int first = a.t_begin > 1 ? a.t_begin : 1;
     if ((first & 1) != colour) ++first;
