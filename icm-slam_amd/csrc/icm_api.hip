@@ -100,6 +100,7 @@ struct icm_handle {
     int lact0 = 0;
     bool brute = false, debug = false, per_beam = false, assoc_kept = false;
     double thr2 = 0.0;  // largest s with sqrt(s) <= dist_thr
+    int hash_slots = 128;  // k_assoc_group's per-pose table; grows to 256 on overflow
     int form = 0;  // 0 moments (lane per pose), 1 per beam, 2 per entry (wave per pose)
     int *pin_i = nullptr;
     double* pin_d = nullptr;  // pinned staging: raw map download (3L)
@@ -459,23 +460,35 @@ int icm_sweep_local(icm_handle* h) {
     GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p};
     const bool dbg = h->debug || h->per_beam;
     h->assoc_kept = dbg;
-#define ASSOC_GROUP(PRE, DBG)                                                                                      \
-    TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG><<<nbw, kBlock, 0, h->stream>>>(                             \
+#define ASSOC_GROUP(PRE, DBG, HS)                                                                                  \
+    TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS><<<nbw, kBlock, 0, h->stream>>>(                         \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
         h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p)))
-    if (h->brute) {
+#define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
+    if (h->brute)
         TIMED(h, KID_ASSOC_BRUTE, (k_associate_brute<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->mapx.p, h->mapy.p, km, h->cfg.dist_thr, h->label.p)));
-        if (dbg) ASSOC_GROUP(true, true); else ASSOC_GROUP(true, false);
-    } else {
-        if (dbg) ASSOC_GROUP(false, true); else ASSOC_GROUP(false, false);
-    }
-#undef ASSOC_GROUP
     const int ntiles = (nloc + kScanTile - 1) / kScanTile;
-    TIMED(h, KID_SCAN, (k_scan_tiles<<<ntiles, kBlock, 0, h->stream>>>(h->nent.p, h->isnew.p, h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc)));
-    TIMED(h, KID_SCAN, (k_scan_fix<<<ntiles, kBlock, 0, h->stream>>>(h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc, ntiles)));
-    HIPCHK(h, hipMemcpyAsync(h->pin_i, h->ent_off.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->pin_i + 1, h->new_rank.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    for (;;) {
+        if (h->brute) {
+            if (dbg) ASSOC_GROUP_HS(true, true); else ASSOC_GROUP_HS(true, false);
+        } else {
+            if (dbg) ASSOC_GROUP_HS(false, true); else ASSOC_GROUP_HS(false, false);
+        }
+        TIMED(h, KID_SCAN, (k_scan_tiles<<<ntiles, kBlock, 0, h->stream>>>(h->nent.p, h->isnew.p, h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc)));
+        TIMED(h, KID_SCAN, (k_scan_fix<<<ntiles, kBlock, 0, h->stream>>>(h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc, ntiles)));
+        HIPCHK(h, hipMemcpyAsync(h->pin_i, h->ent_off.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 1, h->new_rank.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->pin_i[2] && h->hash_slots == 128) {  // a scan with > 96 distinct landmarks: use the larger table from now on
+            h->hash_slots = 256;
+            HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
+            continue;
+        }
+        break;
+    }
+#undef ASSOC_GROUP_HS
+#undef ASSOC_GROUP
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->E = h->pin_i[0];
     h->n_new_loc = h->pin_i[1];

@@ -25,8 +25,6 @@ namespace icm {
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kHash = 256;      // LDS hash slots per pose (distinct landmarks of one scan)
-constexpr int kGroupCap = 192;  // ... of which at most this many may be used
 constexpr int kEmpty = (int)0x80000000;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
@@ -441,16 +439,22 @@ __device__ __forceinline__ void seg_step(bool take, double& ax, double& ay) {
     }
 }
 
+// HS = hash slots per pose; at most 3/4 of them may be used (distinct landmarks of one scan).
+// HS = 128 keeps the kernel at 14 KB of LDS and 64 VGPRs = 8 waves per SIMD (the kernel waits
+// on memory 2/3 of the time, so occupancy matters); a scan that overflows it makes the host
+// relaunch the sweep's phase A with HS = 256.
+template <int HS>
 struct PoseTable {
-    int key[kHash];
-    int cnt[kHash];
-    int owner[kHash];
-    double sx[kHash];
-    double sy[kHash];
+    int key[HS];
+    int cnt[HS];
+    int owner[HS];
+    double sx[HS];
+    double sy[HS];
 };
 
-template <bool PRELABEL, bool DEBUG>
-__global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
+template <bool PRELABEL, bool DEBUG, int HS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? 8 : 4, HS == 128 ? 8 : 5)))
+void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int t_begin, int nloc, const int* __restrict__ boff,
                                                         const double* __restrict__ bx, const double* __restrict__ by,
                                                         GridView g, double thr, double thr2, int* __restrict__ label,
@@ -458,11 +462,13 @@ __global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict
                                                         int* __restrict__ st_k, double* __restrict__ st_sbx,
                                                         double* __restrict__ st_sby, int* __restrict__ nent_out,
                                                         int* __restrict__ isnew_out, int* __restrict__ flags) {
-    __shared__ PoseTable tables[kWavesPerBlock];
+    constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
+    constexpr int kHashShift = HS == 128 ? 25 : 24;
+    __shared__ PoseTable<HS> tables[kWavesPerBlock];
     const int lane = lane_id();
     const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (tl >= nloc) return;
-    PoseTable& T = tables[wave_in_block()];
+    PoseTable<HS>& T = tables[wave_in_block()];
     const int j0 = boff[tl], j1 = boff[tl + 1];
     if (j0 == j1) {
         if (lane == 0) {
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void k_assoc_group(const double* __restrict
         int slot = 0;
         bool inserted = false;
         if (tail) {
-            slot = (int)(((unsigned)lab * 2654435761u) >> 24);
+            slot = (int)(((unsigned)lab * 2654435761u) >> kHashShift);
             for (;;) {
                 const int k = T.key[slot];
                 if (k == lab) break;

@@ -248,3 +248,58 @@ def test_s1_full_size_against_c_oracle():
         assert K == lac and np.array_equal(cnt, cntc) and np.abs(mv - mvc).max() <= 1e-9
         assert d_x.max() <= 5e-3 and (d_x > 1e-9).sum() <= 10
     eng.close()
+
+
+def _dense_ring_case():
+    """360 beams sweeping a ring of landmarks on a 0.13 m grid at ~3 m: neighbouring beams are
+    ~0.05 m apart (so the isolated-beam filter keeps them) and hit a new landmark every couple
+    of beams -> far more than 96 distinct landmarks in one scan."""
+    B, T = 360, 6
+    g = np.arange(-30, 31) * 0.13
+    gx, gy = np.meshgrid(g, g)
+    lm = np.stack((gx.ravel(), gy.ravel()))
+    rr = np.hypot(lm[0], lm[1])
+    lm = lm[:, (rr > 2.6) & (rr < 3.4)]
+    ang = np.arange(B) * np.pi / 180.0
+    x_true = np.zeros((3, T))
+    x_true[2] = np.pi / 2
+    x_true[0] = 0.002 * np.arange(T)
+    scans = np.full((B, T), 10.0)
+    for t in range(T):
+        a = ang + x_true[2, t] - np.pi / 2
+        p = x_true[:2, [t]] + 3.0 * np.stack((np.cos(a), np.sin(a)))
+        j = np.argmin(np.hypot(lm[0][:, None] - p[0][None, :], lm[1][:, None] - p[1][None, :]), axis=0)
+        scans[:, t] = np.hypot(lm[0, j] - x_true[0, t], lm[1, j] - x_true[1, t])
+    u = np.zeros((2, T))
+    u[0] = 0.02
+    cfgd = dict(N=1, deltat=0.1, L=4000, Q=[1, 1], R=[1, 1, 1], cte_odom=1.0, cota=1.0, dist_thr=0.09,
+                dist_thr_obs=1.0, rango_laser_max=10.0, radio=0.0)
+    return lm, scans, x_true, u, cfgd
+
+
+def test_scan_with_many_distinct_landmarks_grows_the_hash_table():
+    """A scan touching > 96 distinct landmarks overflows the default 128-slot per-pose table of
+    k_assoc_group; the sweep relaunches phase A with 256 slots and still matches the oracle."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from oracle import c_oracle as co
+    lm, scans, x_true, u, cfgd = _dense_ring_case()
+    cfg = ConfigICM(D=cfgd)
+    odo = x_true.copy()
+    T = x_true.shape[1]
+    eng = SweepEngine(cfg)
+    eng.upload(scans, odo, u)
+    eng.set_debug(True)
+    x = x_true.copy()
+    mo, cnt, K = eng.sweep(lm, x, x_true[:, 0], lm.shape[1], "redblack")
+    lab = eng.association()[0]
+    off = eng.kept_beams()[0]
+    per_pose = [len(set(lab[off[t]:off[t + 1]])) for t in range(T)]
+    eng.close()
+    print("distinct labels per pose:", per_pose)
+    assert 96 < max(per_pose) <= 192, "the case must overflow the 128-slot table (and fit the 256-slot one)"
+    keptc = co.prefilter(cfg, scans)
+    xc = x_true.copy()
+    mc, cntc, Kc, _ = co.sweep(cfg, keptc, u, odo, x_true[:, 0], lm, xc, lm.shape[1], "redblack")
+    assert K == Kc and np.array_equal(cnt, cntc) and np.abs(mo[:, :K] - mc).max() <= 1e-9
+    assert np.abs(x - xc).max() <= 1e-9
