@@ -71,6 +71,7 @@ struct icm_handle {
     // state
     DevBuf<double> x_own, x0;
     double* x = nullptr;  // (T,3): x_own or a bound external buffer
+    bool x_external = false;
     std::vector<double> h_map;  // current mapa_viejo (2,K) row-major
     int64_t K = 0, lact = 0;
     std::vector<double> h_counts;  // cant_obs_i after the last filtrar (L)
@@ -382,7 +383,7 @@ int icm_set_state(icm_handle* h, const double* x, const double* x0, const double
     if (lact_in > h->cfg.L) FAIL(h, ICM_ERR_INDEX, "icm_set_state: landmarks_actuales > L");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t T = (size_t)h->T;
-    if (!h->x) {
+    if (!h->x_external) {  // (re)size with the sequence: a handle may be re-used for a longer one
         HIPCHK(h, h->x_own.reserve(3 * T));
         h->x = h->x_own.p;
     }
@@ -421,12 +422,13 @@ int icm_bind_pose_buffer(icm_handle* h, void* x_dev) {
     if (!h) return ICM_ERR_ARG;
     if (!x_dev) FAIL(h, ICM_ERR_ARG, "icm_bind_pose_buffer: null buffer");
     h->x = reinterpret_cast<double*>(x_dev);
+    h->x_external = true;
     return ICM_OK;
 }
 
 void* icm_pose_buffer(icm_handle* h) {
     if (!h) return nullptr;
-    if (!h->x) {
+    if (!h->x_external) {
         (void)hipSetDevice(h->device);
         if (h->x_own.reserve(3 * (size_t)h->T) != hipSuccess) return nullptr;
         h->x = h->x_own.p;
@@ -580,9 +582,10 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     a.tgt = h->tgt.p; a.pose_c = h->pose_c.p; a.pose_m = h->pose_m.p;
     a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
     a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
-    if (h->debug && !h->diag.p) {
+    if (h->debug) {
+        const bool fresh = h->diag.cap < 3 * (size_t)h->T;
         HIPCHK(h, h->diag.reserve(3 * (size_t)h->T));
-        HIPCHK(h, hipMemsetAsync(h->diag.p, 0, 3 * (size_t)h->T * sizeof(double), h->stream));
+        if (fresh) HIPCHK(h, hipMemsetAsync(h->diag.p, 0, 3 * (size_t)h->T * sizeof(double), h->stream));
     }
     a.diag = h->debug ? h->diag.p : nullptr;
     if (schedule == ICM_SCHEDULE_SEQUENTIAL) {

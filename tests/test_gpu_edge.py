@@ -303,3 +303,24 @@ def test_scan_with_many_distinct_landmarks_grows_the_hash_table():
     mc, cntc, Kc, _ = co.sweep(cfg, keptc, u, odo, x_true[:, 0], lm, xc, lm.shape[1], "redblack")
     assert K == Kc and np.array_equal(cnt, cntc) and np.abs(mo[:, :K] - mc).max() <= 1e-9
     assert np.abs(x - xc).max() <= 1e-9
+
+
+def test_handle_reuse_with_longer_sequence():
+    """One handle, a short sequence then a longer one (ICM_ROS re-uploads when its data change)."""
+    from icmslam_hip import SweepEngine
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    eng = SweepEngine(Cfg(cota=20.0))
+    outs = []
+    for T in (150, 600):
+        eng.upload(zz[:, :T], odo[:, :T], u[:, :T])
+        x = np.ascontiguousarray(init["x_init"][:, :T]).copy()
+        mo, co, K = eng.sweep(init["map_init"], x, odo[:, 0], 11, "redblack")
+        outs.append((x, mo[:, :K]))
+    eng.close()
+    e2 = SweepEngine(Cfg(cota=20.0))
+    e2.upload(zz[:, :600], odo[:, :600], u[:, :600])
+    x2 = np.ascontiguousarray(init["x_init"][:, :600]).copy()
+    mo2, co2, K2 = e2.sweep(init["map_init"], x2, odo[:, 0], 11, "redblack")
+    e2.close()
+    assert np.array_equal(outs[1][0], x2) and np.array_equal(outs[1][1], mo2[:, :K2])
