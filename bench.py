@@ -32,6 +32,8 @@ for p in (ROOT, os.path.join(ROOT, "icm-slam_amd")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 FP64 FMA lanes x 2 x 2.4 GHz (no MFMA on this path)
+FLOP_PER_ENERGY_EVAL = 180    # moment-form fun_xn: trig 24, observation quadratic form 67, priors 87
 
 
 def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch):
@@ -204,21 +206,46 @@ def main():
         nl = n / nroof
         abytes = algorithmic_bytes(dom, st["kept_beams"], st["entries"], eng.nloc, eng.L, nl)
         ach = abytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        def hbm_roof(kname):
+            ms_k, n_k = kt[kname]
+            ab = algorithmic_bytes(kname, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof)
+            a_gbs = ab / (ms_k / n_k * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": kname, "achieved": round(a_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(a_gbs / HBM_PEAK_GBS, 5), "traffic": traffic_of(kname),
+                    "avg_launch_ms": round(ms_k / n_k, 4), "launches_per_sweep": n_k / nroof,
+                    "algorithmic_bytes_per_launch": int(ab)}
+
+        def traffic_of(kname):
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
             try:
-                traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
+                return json.load(open(tf)).get(args.workload, {}).get(kname)
             except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 4), "launches_per_sweep": nl,
-                "algorithmic_bytes_per_launch": int(abytes),
-                "kernels_ms_per_sweep": {k: round(v[0] / nroof, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
-                "kernels": per_kernel,
-                "note": "k_solve is FP64-VALU/latency bound (one lane per pose, ~60 dependent energy evaluations), "
-                        "k_assoc_group is the HBM-streaming kernel; k_filtrar_grid runs on a side stream under the solves"}
+                return None
+
+        stream_kernel = max((k for k in kt if k not in ("k_filtrar_grid", "k_solve")), key=lambda k: kt[k][0])
+        if dom == "k_solve":
+            # the solves are not a bandwidth kernel: one lane per pose runs ~85 dependent energy
+            # evaluations from registers.  Their roofline is the FP64 vector rate; the flops are the
+            # measured number of energy evaluations x the flops of one evaluation.
+            eng.set_debug(True)
+            step()
+            fence()
+            nfev = float(eng.solve_diag()[:, 2].sum())
+            eng.set_debug(False)
+            flops = nfev * FLOP_PER_ENERGY_EVAL / nl
+            tfl = flops / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "valu_fp64", "kernel": dom, "achieved": round(tfl, 3), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tfl / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic_of(dom), "avg_launch_ms": round(avg_ms, 4),
+                    "launches_per_sweep": nl, "energy_evaluations_per_sweep": int(nfev),
+                    "flop_per_evaluation": FLOP_PER_ENERGY_EVAL, "algorithmic_bytes_per_launch": int(abytes)}
+        else:
+            roof = hbm_roof(dom)
+        roof["hbm_stream_kernel"] = hbm_roof(stream_kernel)
+        roof["kernels_ms_per_sweep"] = {k: round(v[0] / nroof, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}
+        roof["kernels"] = per_kernel
+        roof["note"] = ("k_solve: FP64-VALU/latency bound (one lane per pose, a launch lasts as long as its slowest pose's chain "
+                        "of Nelder-Mead evaluations); k_assoc_group: the HBM-streaming kernel; k_filtrar_grid: one workgroup on "
+                        "a side stream under the solves")
         Kt = st["entries"] / max(eng.nloc, 1)
         sweep_bytes = survey_bytes_per_pose(B, Kt, K, T) * (T - 1)
         roof["sweep_algorithmic_GBps"] = round(sweep_bytes / (ms_per_step * 1e-3) / 1e9, 2)
