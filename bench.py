@@ -45,9 +45,9 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch):
         # (label 4, k 4, sum bx 8, sum by 8) per distinct landmark of the scan; counts/flags
         "k_assoc_group": nnz * 16 + E * 24 + nloc * (24 + 8 + 8),
         "k_associate_brute": nnz * (16 + 4) + nloc * 32,
-        # staged entries in (24); out: key 4, id 4, k 4, mean b 16, world sums 32, rotated mean 16;
+        # staged entries in (24); out: key 4, id 4, k 4, world sums 32, rotated mean offset 16;
         # per pose: pose 24, second moments 24, scatter 24, offsets 8
-        "k_compact": E * 24 + E * 76 + nloc * 80,
+        "k_compact": E * 24 + E * 60 + nloc * 80,
         "radix_sort_pairs": E * 8 * 2 * 2,
         "k_lm_bounds": (L + 1) * 4,
         "k_lm_scan_totals": E * (4 + 32) + L * (8 + 24),

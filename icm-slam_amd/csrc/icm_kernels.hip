@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(const double* __restrict__ x
         e_key[e0 + q] = (unsigned)lab;
         e_val[e0 + q] = e0 + q;
         e_k[e0 + q] = k;
-        e_b[e0 + q] = make_double2(sbx / kd, sby / kd);
+        if (e_b) e_b[e0 + q] = make_double2(sbx / kd, sby / kd);  // per-entry energy form only
         const double rx = ct * sbx - st * sby, ry = st * sbx + ct * sby;  // R sum b
         e_w[e0 + q] = EntW{kd * px + rx, kd * py + ry, kd, 0.0};
         e_wr[e0 + q] = make_double2(rx / kd, ry / kd);
