@@ -530,7 +530,7 @@ int icm_sweep_targets(icm_handle* h) {
         TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, nullptr, nullptr, nullptr, h->tgt.p, nullptr, h->y_raw.p, h->cnt_raw.p)));
     }
     if (h->form == 0)
-        TIMED(h, KID_POSE_MOMENTS, (k_pose_moments<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->ent_off.p, h->e_k.p, h->e_wr.p, h->tgt.p, h->pose_c.p, h->pose_m.p)));
+        TIMED(h, KID_POSE_MOMENTS, (k_pose_moments<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->ent_off.p, h->e_k.p, h->e_wr.p, h->tgt.p, h->pose_c.p, h->pose_m.p)));
     if (h->assoc_kept)
         TIMED(h, KID_BEAM_TARGETS, (k_beam_targets<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->bloc.p, h->tgt.p, h->btx.p, h->bty.p)));
     HIPCHK(h, hipGetLastError());

@@ -1138,22 +1138,37 @@ __device__ __forceinline__ void solve_pose(const SolveArgs& a, int tg, const dou
     }
 }
 
-// Moments of the moment-form energy (icm_device.hpp, PoseMoments): one wave per pose reduces
-// its entries; stored [17][nloc] so that the lane-per-pose solver reads them coalesced.
+// Moments of the moment-form energy (icm_device.hpp, PoseMoments).  A pose has ~40 entries, so
+// one DPP row (16 lanes) per pose: four poses per wavefront, lanes stride over the pose's
+// entries, 14 row reductions (4 DPP steps each, no cross-row traffic).  Stored [17][nloc] so
+// that the lane-per-pose solver reads them coalesced.
+__device__ __forceinline__ double row_sum16(double v) {  // sum over the 16 lanes of a DPP row, in every lane
+    v += dpp_mov<0x121, 0xF>(v);  // row_ror:1
+    v += dpp_mov<0x122, 0xF>(v);  // row_ror:2
+    v += dpp_mov<0x124, 0xF>(v);  // row_ror:4
+    v += dpp_mov<0x128, 0xF>(v);  // row_ror:8
+    return v;
+}
+
 __global__ __launch_bounds__(kBlock) void k_pose_moments(const double* __restrict__ x, const double* __restrict__ x0,
                                                          int t_begin, int nloc, const int* __restrict__ ent_off,
                                                          const int* __restrict__ e_k, const double2* __restrict__ e_wr,
                                                          const double2* __restrict__ tgt, const double* __restrict__ pose_c,
                                                          double* __restrict__ pose_m) {
-    const int lane = lane_id();
-    const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
-    if (tl >= nloc) return;
-    double px, py, th;
-    pose_of(x, x0, t_begin + tl, px, py, th);
+    const int sub = threadIdx.x & 15;
+    const int tl = (blockIdx.x * kBlock + threadIdx.x) >> 4;
+    const bool live = tl < nloc;
+    double px = 0.0, py = 0.0, th = 0.0;
+    int e0 = 0, e1 = 0;
+    if (live) {
+        pose_of(x, x0, t_begin + tl, px, py, th);
+        e0 = ent_off[tl];
+        e1 = ent_off[tl + 1];
+    }
     double m[kMomentCount];
 #pragma unroll
     for (int q = 0; q < kMomentCount; ++q) m[q] = 0.0;
-    for (int e = ent_off[tl] + lane; e < ent_off[tl + 1]; e += kWave) {
+    for (int e = e0 + sub; e < e1; e += 16) {
         const double2 w = e_wr[e], tg = tgt[e];
         const double k = (double)e_k[e], wx = w.x, wy = w.y;
         const double rx = (px + wx) - tg.x, ry = (py + wy) - tg.y;
@@ -1163,8 +1178,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments(const double* __restric
         m[12] += k * rx * rx; m[13] += k * ry * ry;
     }
 #pragma unroll
-    for (int q = 0; q < kMomentCount; ++q) m[q] = wave_sum(m[q]);
-    if (lane == 0) {
+    for (int q = 0; q < kMomentCount; ++q) m[q] = row_sum16(m[q]);
+    if (live && sub == 0) {
 #pragma unroll
         for (int q = 0; q < kMomentCount; ++q) pose_m[(size_t)q * nloc + tl] = m[q];
         pose_m[(size_t)14 * nloc + tl] = pose_c[3 * (size_t)tl];
