@@ -499,7 +499,7 @@ int icm_sweep_local(icm_handle* h) {
         FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
     const int nlab = h->lact0 + (int)h->n_new_loc;
     const int E = (int)h->E;
-    TIMED(h, KID_COMPACT, (k_compact<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, h->e_key.p, h->e_val.p, h->e_k.p, h->form == 2 ? h->e_b.p : nullptr, h->e_w.p, h->e_wr.p, h->pose_c.p)));
+    TIMED(h, KID_COMPACT, (k_compact<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, h->e_key.p, h->e_val.p, h->e_k.p, h->form == 2 ? h->e_b.p : nullptr, h->e_w.p, h->e_wr.p, h->pose_c.p)));
     int bits = 1;
     while ((1ll << bits) < (int64_t)nlab + 1) ++bits;
     size_t tmp_bytes = h->sort_tmp.cap;

@@ -32,6 +32,13 @@ __device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
 __device__ __forceinline__ int prefix_count(unsigned long long mask, int lane) {
     return __popcll(mask & ((1ull << lane) - 1ull));
 }
+__device__ __forceinline__ double row_sum16(double v) {  // sum over the 16 lanes of a DPP row, in every lane
+    v += dpp_mov<0x121, 0xF>(v);  // row_ror:1
+    v += dpp_mov<0x122, 0xF>(v);  // row_ror:2
+    v += dpp_mov<0x124, 0xF>(v);  // row_ror:4
+    v += dpp_mov<0x128, 0xF>(v);  // row_ror:8
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------
 // Two-level exclusive scan of two int arrays at once (entry counts, new-landmark flags).
@@ -629,17 +636,24 @@ __global__ __launch_bounds__(kBlock) void k_compact(const double* __restrict__ x
                                                     int* __restrict__ e_k, double2* __restrict__ e_b,
                                                     EntW* __restrict__ e_w, double2* __restrict__ e_wr,
                                                     double* __restrict__ pose_c) {
-    const int lane = lane_id();
-    const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
-    if (tl >= nloc) return;
-    const int j0 = boff[tl], e0 = ent_off[tl], n = ent_off[tl + 1] - e0;
-    double px, py, th;
-    pose_of(x, x0, t_begin + tl, px, py, th);
+    // one DPP row (16 lanes) per pose, four poses per wavefront (a pose has ~40 entries)
+    const int sub = threadIdx.x & 15;
+    const int tl = (blockIdx.x * kBlock + threadIdx.x) >> 4;
+    const bool live = tl < nloc;
+    int j0 = 0, e0 = 0, n = 0, nrank = 0;
+    double px = 0.0, py = 0.0, th = 0.0;
+    if (live) {
+        j0 = boff[tl];
+        e0 = ent_off[tl];
+        n = ent_off[tl + 1] - e0;
+        nrank = new_rank[tl];
+        pose_of(x, x0, t_begin + tl, px, py, th);
+    }
     const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
     double mxx = 0.0, mxy = 0.0, myy = 0.0;
-    for (int q = lane; q < n; q += kWave) {
+    for (int q = sub; q < n; q += 16) {
         int lab = st_label[j0 + q];
-        if (lab < 0) lab = lact0 + new_rank[tl];
+        if (lab < 0) lab = lact0 + nrank;
         const int k = st_k[j0 + q];
         const double kd = (double)k, sbx = st_sbx[j0 + q], sby = st_sby[j0 + q];
         e_key[e0 + q] = (unsigned)lab;
@@ -653,10 +667,10 @@ __global__ __launch_bounds__(kBlock) void k_compact(const double* __restrict__ x
         mxy += sbx * sby / kd;
         myy += sby * sby / kd;
     }
-    mxx = wave_sum(mxx);
-    mxy = wave_sum(mxy);
-    myy = wave_sum(myy);
-    if (lane == 0) {
+    mxx = row_sum16(mxx);
+    mxy = row_sum16(mxy);
+    myy = row_sum16(myy);
+    if (live && sub == 0) {
         pose_c[3 * (size_t)tl] = pose_s2[3 * (size_t)tl] - mxx;
         pose_c[3 * (size_t)tl + 1] = pose_s2[3 * (size_t)tl + 1] - mxy;
         pose_c[3 * (size_t)tl + 2] = pose_s2[3 * (size_t)tl + 2] - myy;
@@ -1142,14 +1156,6 @@ __device__ __forceinline__ void solve_pose(const SolveArgs& a, int tg, const dou
 // one DPP row (16 lanes) per pose: four poses per wavefront, lanes stride over the pose's
 // entries, 14 row reductions (4 DPP steps each, no cross-row traffic).  Stored [17][nloc] so
 // that the lane-per-pose solver reads them coalesced.
-__device__ __forceinline__ double row_sum16(double v) {  // sum over the 16 lanes of a DPP row, in every lane
-    v += dpp_mov<0x121, 0xF>(v);  // row_ror:1
-    v += dpp_mov<0x122, 0xF>(v);  // row_ror:2
-    v += dpp_mov<0x124, 0xF>(v);  // row_ror:4
-    v += dpp_mov<0x128, 0xF>(v);  // row_ror:8
-    return v;
-}
-
 __global__ __launch_bounds__(kBlock) void k_pose_moments(const double* __restrict__ x, const double* __restrict__ x0,
                                                          int t_begin, int nloc, const int* __restrict__ ent_off,
                                                          const int* __restrict__ e_k, const double2* __restrict__ e_wr,
