@@ -1,7 +1,9 @@
 // C-ABI of the MI355X-native ICM sweep (include/icmslam.h): handle, HBM buffers, sweep
-// orchestration.  All device work goes to one HIP stream; the only host round trips per
-// sweep are two small counter reads (entry / new-landmark counts) and the raw-map download
-// for the host-side Mapa.filtrar.
+// orchestration.  Device work goes to one HIP stream, plus a side stream for the fused map
+// filter (k_filtrar_grid) and the asynchronous raw-map download, both overlapped with the pose
+// solves.  Host round trips per sweep: one 12-byte read-back (entry / new-landmark counts --
+// rocPRIM needs the sort size) and one 16-byte read-back of the filter result; Mapa.filtrar
+// falls back to the host routine only when landmarks have to be merged.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -494,7 +496,7 @@ int icm_sweep_local(icm_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->E = h->pin_i[0];
     h->n_new_loc = h->pin_i[1];
-    if (h->pin_i[2]) FAIL(h, ICM_ERR_CAPACITY, "sweep: a scan touched more than 192 distinct landmarks");
+    if (h->pin_i[2]) FAIL(h, ICM_ERR_CAPACITY, "sweep: a scan touched more than 192 distinct landmarks (limit of the per-pose table)");
     if ((int64_t)h->lact0 + h->n_new_loc > L)
         FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
     const int nlab = h->lact0 + (int)h->n_new_loc;

@@ -6,17 +6,22 @@
 //                              (pose, landmark) ENTRY per distinct label of the scan with
 //                              the count and the sums of the body / world points
 //             k_scan_*         entry offsets, ranks of poses that create a landmark
-//             k_compact        entries -> pose-major compact arrays, fresh ids for new landmarks
+//             k_compact        entries -> pose-major compact records, fresh ids for new landmarks
 //             (radix sort of the entry ids by label, rocPRIM)      -> CSR by landmark
 //   phase B/D k_lm_scan        one wave per landmark: time-ordered prefix of its entries
 //                              -> running-mean target of every entry, landmark totals
 //             k_stats_prefix   totals + exclusive prefix over lower ranks (after all-gather)
-//   phase C   k_solve_*        one wavefront per pose: Nelder-Mead on the conditional energy,
-//                              the pose's entries held one per lane in registers
+//             k_filtrar_grid   Mapa.filtrar + search grid of the refined map (one workgroup,
+//                              side stream, under the solves)
+//   phase C   k_pose_moments   14 moment sums of the pose's observation energy
+//             k_solve_m_*      Nelder-Mead on the conditional energy in moment form:
+//                              ONE LANE per pose, everything in registers
+//             k_solve_* (wave per pose, per-beam / per-entry energy): cross-checks
+//   init      k_init_pass      the causal initialisation pass (one wave walks the sequence)
 //
-// Mapping rule everywhere: one wavefront (64 lanes) per pose (or per landmark), lanes stride
-// over the pose's kept beams / entries; 256-thread workgroups = 4 poses.  No MFMA: there is
-// no dense contraction on this path.
+// Mapping: phase A one wavefront per pose (lanes over its kept beams), entry kernels one DPP
+// row (16 lanes) per pose, landmark kernels one wavefront per landmark, solves one lane per
+// pose; 256-thread workgroups.  No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
 
 #include "icm_device.hpp"
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_associate_brute(const double* __rest
 // sum of world points = k p + R sum b) and of the pose energy (icm_device.hpp, Items).
 //
 // Beams arrive sorted by bearing, so equal labels form runs: a wave-level segmented scan
-// reduces each run, and the run tails fold their totals into a 256-slot LDS hash table keyed
+// reduces each run, and the run tails fold their totals into an LDS hash table keyed
 // by label (linear probing, claimed with ds_cmpst).  Deterministic: runs are folded chunk
 // by chunk, and two runs of one label inside a chunk are folded in lane order.
 // Entries are staged at the front of the pose's beam range, in slot order.
@@ -623,8 +628,8 @@ struct EntW {
 
 // Entries -> pose-major compact arrays.  The gated-out group of a pose gets the fresh id
 // lact0 + (number of earlier poses that created a landmark) (phase B).
-// Per entry: count, mean body point (energy item), sum of world points k p + R sum b
-// (running-mean term).  Per pose: the pooled within-entry scatter C = sum_j b b^T - sum_e k
+// Per entry: count, sum of world points k p + R sum b (running-mean term), mean offset
+// R bbar (moment-form energy) [, mean body point for the per-entry energy form].  Per pose: the pooled within-entry scatter C = sum_j b b^T - sum_e k
 // bbar bbar^T of the energy's scatter term.
 __global__ __launch_bounds__(kBlock) void k_compact(const double* __restrict__ x, const double* __restrict__ x0,
                                                     int t_begin, int nloc, const int* __restrict__ boff,
