@@ -156,6 +156,7 @@ __device__ __forceinline__ double obs_energy_reg(const SolveCtx& c, const Items&
 struct PoseMoments {
     double S, Swx, Swy, Srx, Sry, Swxx, Swyy, Swxy, Swxrx, Swyrx, Swxry, Swyry, Srxx, Sryy;
     double cxx, cxy, cyy;      // pooled within-entry scatter (body frame)
+    double sc_iso;             // Q0 (cxx + cyy): the scatter term when Q is isotropic
     double pox, poy, tho, co, so;   // expansion point: p_o, th_o, cos/sin th_o
 };
 constexpr int kMomentCount = 14;
@@ -189,10 +190,14 @@ __device__ __forceinline__ double moments_energy(const SolveCtx& c, const PoseMo
                      2.0 * ((dx * ((al * m.Swx - be * m.Swy) + m.Srx) + al * (m.Swxrx - be * m.Swxy)) - be * m.Swyrx);
     const double Y = (((m.S * dy) * dy + (al * al) * m.Swyy) + ((be * be) * m.Swxx + m.Sryy)) +
                      2.0 * ((dy * ((al * m.Swy + be * m.Swx) + m.Sry) + al * (m.Swyry + be * m.Swxy)) + be * m.Swxry);
-    // scatter term with cos(th - pi/2) = sin th, sin(th - pi/2) = -cos th
-    const double ct = sth, st = -cth;
-    const double sc = ((c.Q0 * ct * ct + c.Q1 * st * st) * m.cxx + 2.0 * (ct * st) * (c.Q1 - c.Q0) * m.cxy) +
-                      (c.Q0 * st * st + c.Q1 * ct * ct) * m.cyy;
+    // scatter term tr(R^T Q R C) with cos(th - pi/2) = sin th, sin(th - pi/2) = -cos th; for an
+    // isotropic Q it does not depend on the pose: Q0 (cxx + cyy), precomputed in m.sc_iso
+    double sc = m.sc_iso;
+    if (c.Q0 != c.Q1) {
+        const double ct = sth, st = -cth;
+        sc = ((c.Q0 * ct * ct + c.Q1 * st * st) * m.cxx + 2.0 * (ct * st) * (c.Q1 - c.Q0) * m.cxy) +
+             (c.Q0 * st * st + c.Q1 * ct * ct) * m.cyy;
+    }
     return (c.Q0 * X + c.Q1 * Y) + sc;
 }
 
