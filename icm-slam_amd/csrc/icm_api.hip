@@ -104,6 +104,7 @@ struct icm_handle {
     bool brute = false, debug = false, per_beam = false, assoc_kept = false;
     double thr2 = 0.0;  // largest s with sqrt(s) <= dist_thr
     int hash_slots = 128;  // k_assoc_group's per-pose table; grows to 256 on overflow
+    int solve_quad = -1;   // -1 automatic, 0 one lane per pose, 1 one quad per pose
     int form = 0;  // 0 moments (lane per pose), 1 per beam, 2 per entry (wave per pose)
     int *pin_i = nullptr;
     double* pin_d = nullptr;  // pinned staging: raw map download (3L)
@@ -602,10 +603,13 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
             if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_colour<true><<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, col)));
             else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_colour<false><<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, col)));
             else {
-                // 64 poses per wavefront.  (Measured: spreading a colour over more, partly filled
-                // waves never helps -- the launch lasts as long as its slowest pose's chain of
-                // Nelder-Mead iterations, and extra waves only add issue pressure.)
-                TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_waves((nw + kWave - 1) / kWave), kBlock, 0, h->stream>>>(a, col)));
+                // Throughput form: one lane per pose (64 poses per wave).  Latency form: one DPP quad
+                // per pose evaluating the four candidate points of an iteration at once -- used when
+                // a colour has too few poses to fill the chip's 1024 SIMDs even at 16 poses per wave
+                // (small sequences, small shards), where only the length of the serial chain counts.
+                const bool quad = h->solve_quad == 1 || (h->solve_quad < 0 && (int64_t)nw * 4 <= (int64_t)1024 * kWave);
+                if (quad) TIMED(h, KID_SOLVE, (k_solve_mq_colour<<<nblocks_threads((int64_t)nw * 4), kBlock, 0, h->stream>>>(a, col)));
+                else TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_waves((nw + kWave - 1) / kWave), kBlock, 0, h->stream>>>(a, col)));
             }
         }
     } else {
@@ -934,6 +938,13 @@ int icm_set_energy_form(icm_handle* h, int form) {
     if (form < 0 || form > 2) FAIL(h, ICM_ERR_ARG, "icm_set_energy_form: form must be 0, 1 or 2");
     h->form = form;
     h->per_beam = form == 1;
+    return ICM_OK;
+}
+
+int icm_set_solve_lanes(icm_handle* h, int mode) {
+    if (!h) return ICM_ERR_ARG;
+    if (mode < -1 || mode > 1) FAIL(h, ICM_ERR_ARG, "icm_set_solve_lanes: mode must be -1, 0 or 1");
+    h->solve_quad = mode;
     return ICM_OK;
 }
 

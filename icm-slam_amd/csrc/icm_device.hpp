@@ -424,4 +424,123 @@ __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double s
     out[4] = (double)it; out[5] = (double)nfev;
 }
 
+// ---------------------------------------------------------------------------------------
+// Latency form of the same Nelder-Mead: FOUR lanes (one DPP quad) per pose.  The reflection,
+// expansion, outside and inside contraction points of an iteration depend only on the centroid
+// and the worst vertex, so the quad evaluates all four at once (lane r evaluates point r) and
+// then takes SciPy's decision from the four values; the three shrink vertices and the four
+// initial vertices are evaluated in parallel the same way.  An iteration then costs ONE energy
+// evaluation of latency instead of up to two (shrink: one instead of three), at four times the
+// arithmetic -- the right trade when there are fewer poses than lanes to fill (small shards,
+// the sequential schedule).  Same arithmetic per point, same decisions, same nfev accounting
+// (only logically evaluated points are counted, maxfun aborts as in the scalar form), so the
+// result is bit-identical to nelder_mead3.
+// ---------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v) {  // value of lane K of the quad, in all four lanes
+    constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);  // quad_perm:[K,K,K,K]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <class F>
+__device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, double st, int role, double out[6]) {
+    const int maxfun = 600, maxiter = 600;
+    const double xatol = 1e-3, fatol = 1e-4;
+    const double grow = 1 + 0.05;
+    Vtx v0{sx, sy, st, 0.0};
+    Vtx v1{sx != 0.0 ? grow * sx : 0.00025, sy, st, 0.0};
+    Vtx v2{sx, sy != 0.0 ? grow * sy : 0.00025, st, 0.0};
+    Vtx v3{sx, sy, st != 0.0 ? grow * st : 0.00025, 0.0};
+    {
+        Vtx c = v0;
+        if (role == 1) c = v1;
+        if (role == 2) c = v2;
+        if (role == 3) c = v3;
+        const double fv = f(c.x, c.y, c.t);
+        v0.f = quad_bcast<0>(fv);
+        v1.f = quad_bcast<1>(fv);
+        v2.f = quad_bcast<2>(fv);
+        v3.f = quad_bcast<3>(fv);
+    }
+    int nfev = 4, it = 1;
+    sort4(v0, v1, v2, v3);
+    // point r of an iteration = ca[r] * xbar + cb[r] * sim[-1]
+    const double ca = role == 0 ? 2.0 : (role == 1 ? 3.0 : (role == 2 ? 1.5 : 0.5));
+    const double cb = role == 0 ? -1.0 : (role == 1 ? -2.0 : (role == 2 ? -0.5 : 0.5));
+    while (nfev < maxfun && it < maxiter) {
+        const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
+        const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
+        if (dx <= xatol && df <= fatol) break;
+        const double bx = ((v0.x + v1.x) + v2.x) / 3.0;
+        const double by = ((v0.y + v1.y) + v2.y) / 3.0;
+        const double bt = ((v0.t + v1.t) + v2.t) / 3.0;
+        // my point (role 0: 2*xbar - sim[-1], written so that it rounds like the scalar form)
+        const double mx = role == 0 ? 2 * bx - v3.x : ca * bx + cb * v3.x;
+        const double my = role == 0 ? 2 * by - v3.y : ca * by + cb * v3.y;
+        const double mt = role == 0 ? 2 * bt - v3.t : ca * bt + cb * v3.t;
+        const double fm = f(mx, my, mt);
+        Vtx r{quad_bcast<0>(mx), quad_bcast<0>(my), quad_bcast<0>(mt), quad_bcast<0>(fm)};
+        ++nfev;
+        int kind = 0;
+        if (r.f < v0.f) kind = 1;
+        else if (r.f < v2.f) kind = 0;
+        else if (r.f < v3.f) kind = 2;
+        else kind = 3;
+        bool shrink = false, aborted = false;
+        if (kind != 0) {
+            if (nfev >= maxfun) {
+                aborted = true;
+            } else {
+                Vtx t;
+                if (kind == 1) t = Vtx{quad_bcast<1>(mx), quad_bcast<1>(my), quad_bcast<1>(mt), quad_bcast<1>(fm)};
+                else if (kind == 2) t = Vtx{quad_bcast<2>(mx), quad_bcast<2>(my), quad_bcast<2>(mt), quad_bcast<2>(fm)};
+                else t = Vtx{quad_bcast<3>(mx), quad_bcast<3>(my), quad_bcast<3>(mt), quad_bcast<3>(fm)};
+                ++nfev;
+                if (kind == 1) v3 = (t.f < r.f) ? t : r;
+                else if (kind == 2) { if (t.f <= r.f) v3 = t; else shrink = true; }
+                else { if (t.f < v3.f) v3 = t; else shrink = true; }
+            }
+        } else {
+            v3 = r;
+        }
+        if (shrink) {
+            // sim[j] = sim[0] + sigma (sim[j] - sim[0]), j = 1..3, each followed by its evaluation;
+            // a call beyond maxfun aborts after the vertex was moved (SciPy's order)
+            const int room = maxfun - nfev;  // evaluations still allowed (>= 1 here is not guaranteed)
+            Vtx n1 = v1, n2 = v2, n3 = v3;
+            n1.x = v0.x + 0.5 * (v1.x - v0.x); n1.y = v0.y + 0.5 * (v1.y - v0.y); n1.t = v0.t + 0.5 * (v1.t - v0.t);
+            n2.x = v0.x + 0.5 * (v2.x - v0.x); n2.y = v0.y + 0.5 * (v2.y - v0.y); n2.t = v0.t + 0.5 * (v2.t - v0.t);
+            n3.x = v0.x + 0.5 * (v3.x - v0.x); n3.y = v0.y + 0.5 * (v3.y - v0.y); n3.t = v0.t + 0.5 * (v3.t - v0.t);
+            Vtx c = n1;
+            if (role == 2) c = n2;
+            if (role == 3) c = n3;
+            const double fs = f(c.x, c.y, c.t);
+            n1.f = quad_bcast<1>(fs);
+            n2.f = quad_bcast<2>(fs);
+            n3.f = quad_bcast<3>(fs);
+            if (room >= 3) {
+                v1 = n1; v2 = n2; v3 = n3;
+                nfev += 3;
+            } else {  // vertex `room + 1` is moved but not evaluated, later ones are untouched
+                aborted = true;
+                if (room >= 1) v1 = n1; else { v1.x = n1.x; v1.y = n1.y; v1.t = n1.t; }
+                if (room >= 2) v2 = n2; else if (room == 1) { v2.x = n2.x; v2.y = n2.y; v2.t = n2.t; }
+                if (room == 2) { v3.x = n3.x; v3.y = n3.y; v3.t = n3.t; }
+                nfev += room > 0 ? room : 0;
+            }
+            sort4(v0, v1, v2, v3);
+        } else {
+            cswap(v2, v3);
+            cswap(v1, v2);
+            cswap(v0, v1);
+        }
+        if (aborted) break;
+        ++it;
+    }
+    out[0] = v0.x; out[1] = v0.y; out[2] = v0.t; out[3] = v0.f;
+    out[4] = (double)it; out[5] = (double)nfev;
+}
+
 }  // namespace icm

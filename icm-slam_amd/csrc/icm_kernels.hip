@@ -1199,8 +1199,10 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments(const double* __restric
     }
 }
 
-// One LANE solves pose tg with the moment-form energy.  `prev` = x[:,tg-1] as it stands now.
-__device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, const double prev[3], double res[3]) {
+// One LANE (QUAD: one DPP quad, role = lane & 3) solves pose tg with the moment-form energy.
+// `prev` = x[:,tg-1] as it stands now.
+template <bool QUAD>
+__device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, const double prev[3], double res[3], int role = 0) {
     const int tl = tg - a.t_begin;
     const int n = a.boff[tl + 1] - a.boff[tl];
     const bool last = tg + 1 >= a.T;
@@ -1244,9 +1246,12 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
         sx = c.gax; sy = c.gay; st = c.gat;
     }
     double out[6];
-    nelder_mead3([&](double px, double py, double th) { return pose_energy_moments(c, m, px, py, th); }, sx, sy, st, out);
+    if (QUAD)
+        nelder_mead3_quad([&](double px, double py, double th) { return pose_energy_moments(c, m, px, py, th); }, sx, sy, st, role, out);
+    else
+        nelder_mead3([&](double px, double py, double th) { return pose_energy_moments(c, m, px, py, th); }, sx, sy, st, out);
     res[0] = out[0]; res[1] = out[1]; res[2] = out[2];
-    if (a.diag) {
+    if (a.diag && role == 0) {
         a.diag[3 * (size_t)tg] = out[3];
         a.diag[3 * (size_t)tg + 1] = out[4];
         a.diag[3 * (size_t)tg + 2] = out[5];
@@ -1264,22 +1269,45 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
     if (tg >= a.t_begin + a.nloc) return;
     double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
     double res[3];
-    solve_pose_moments(a, tg, prev, res);
+    solve_pose_moments<false>(a, tg, prev, res);
     a.x[3 * (size_t)tg] = res[0];
     a.x[3 * (size_t)tg + 1] = res[1];
     a.x[3 * (size_t)tg + 2] = res[2];
 }
 
-// Reference order, moment form: a single lane walks the chain t = 1..T-1.
-__global__ __launch_bounds__(kWave) void k_solve_m_sequential(SolveArgs a) {
-    if (threadIdx.x != 0) return;
-    double prev[3] = {a.x[0], a.x[1], a.x[2]};
-    for (int tg = 1; tg < a.T; ++tg) {
-        double res[3];
-        solve_pose_moments(a, tg, prev, res);
+// The same half sweep in latency form: one DPP quad (4 lanes) per pose, 16 poses per wave
+// (nelder_mead3_quad).  Chosen by the host when a colour has too few poses to fill the chip.
+__global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, int colour) {
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int w = gid >> 2, role = gid & 3;
+    int first = a.t_begin > 1 ? a.t_begin : 1;
+    if ((first & 1) != colour) ++first;
+    const int tg = first + 2 * w;
+    if (tg >= a.t_begin + a.nloc) return;  // whole quads leave together
+    double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
+    double res[3];
+    solve_pose_moments<true>(a, tg, prev, res, role);
+    if (role == 0) {
         a.x[3 * (size_t)tg] = res[0];
         a.x[3 * (size_t)tg + 1] = res[1];
         a.x[3 * (size_t)tg + 2] = res[2];
+    }
+}
+
+// Reference order, moment form: one DPP quad walks the chain t = 1..T-1 (latency form of the
+// Nelder-Mead: the chain is strictly serial, so evaluation latency is all that matters).
+__global__ __launch_bounds__(kWave) void k_solve_m_sequential(SolveArgs a) {
+    if (threadIdx.x >= 4) return;
+    const int role = threadIdx.x;
+    double prev[3] = {a.x[0], a.x[1], a.x[2]};
+    for (int tg = 1; tg < a.T; ++tg) {
+        double res[3];
+        solve_pose_moments<true>(a, tg, prev, res, role);
+        if (role == 0) {
+            a.x[3 * (size_t)tg] = res[0];
+            a.x[3 * (size_t)tg + 1] = res[1];
+            a.x[3 * (size_t)tg + 2] = res[2];
+        }
         prev[0] = res[0]; prev[1] = res[1]; prev[2] = res[2];
     }
 }

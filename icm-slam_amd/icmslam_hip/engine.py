@@ -332,6 +332,10 @@ class SweepEngine:
         form = {"moments": 0, "beam": 1, "entry": 2}.get(form, form)
         self._chk(self.lib.icm_set_energy_form(self.h, int(form)))
 
+    def set_solve_lanes(self, mode):
+        """-1 automatic, 0 one lane per pose, 1 one quad per pose (latency form)."""
+        self._chk(self.lib.icm_set_solve_lanes(self.h, int(mode)))
+
     def set_gpu_filtrar(self, on):
         self._chk(self.lib.icm_set_gpu_filtrar(self.h, int(bool(on))))
 

@@ -183,6 +183,12 @@ int icm_get_solve_diag(icm_handle *h, double *out);
  * Forms 1 and 2 exist to cross-check form 0. */
 int icm_set_energy_form(icm_handle *h, int form);
 
+/* Lanes per pose in the red-black solves: 0 = one lane per pose (throughput form), 1 = one DPP
+ * quad per pose evaluating the four candidate points of a Nelder-Mead iteration at once (latency
+ * form, for colours with fewer poses than the chip has lanes), -1 = automatic (default).
+ * Bit-identical results. */
+int icm_set_solve_lanes(icm_handle *h, int mode);
+
 /* Where Mapa.filtrar runs inside a sweep: 1 (default) = fused GPU kernel `k_filtrar_grid`
  * (falls back to the host routine when landmarks have to be merged), 0 = always the host
  * routine icm_filtrar.  Same results. */

@@ -324,3 +324,41 @@ def test_handle_reuse_with_longer_sequence():
     mo2, co2, K2 = e2.sweep(init["map_init"], x2, odo[:, 0], 11, "redblack")
     e2.close()
     assert np.array_equal(outs[1][0], x2) and np.array_equal(outs[1][1], mo2[:, :K2])
+
+
+def test_quad_latency_solver_is_bit_identical():
+    """The four-lanes-per-pose (speculative) Nelder-Mead against the one-lane form: same poses,
+    same iteration / evaluation counts, on the real dataset (red-black) and a synthetic one."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    eng = SweepEngine(Cfg())
+    eng.upload(zz, odo, u)
+    eng.set_debug(True)
+    res = {}
+    for mode in (0, 1):
+        eng.set_solve_lanes(mode)
+        eng.set_state(init["map_init"], init["x_init"], odo[:, 0], 11)
+        for _ in range(2):
+            eng.sweep_device("redblack")
+        res[mode] = (eng.get_state(), eng.solve_diag().copy())
+    eng.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][1], res[1][1])          # f, nit, nfev of every pose
+    assert res[0][1][:, 2].max() > 60
+    wl = make_workload(1900, 100, 180)
+    e2 = SweepEngine(ConfigICM(D=wl.config))
+    e2.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    out = []
+    for mode in (0, 1):
+        e2.set_solve_lanes(mode)
+        e2.set_state(wl.map_init, wl.x_init, wl.x0)
+        for _ in range(3):
+            e2.sweep_device("redblack")
+        out.append(e2.get_state())
+    e2.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
