@@ -9,9 +9,14 @@ A "step" is one full ICM sweep (reference `iterations_process_offline`, scripts/
 association of every kept beam, running-mean map, one Nelder-Mead solve per pose, map
 prune/merge) over the whole synthetic sequence, which is resident in HBM when timing starts.
 Poses are solved in the red-black order (the reference's sequential order is one dependent
-chain of T-1 solves and is used for parity, not throughput).  With N > 1 the SAME sequence is
-sharded by pose blocks over the ranks (strong scaling), with one all-gather of the landmark
-sufficient statistics and the pose-block exchanges per sweep.
+chain of T-1 solves and is used for parity, not throughput).  With N > 1 ONE sequence is sharded
+by contiguous pose blocks over the ranks, with one all-gather of the landmark sufficient
+statistics and two 48-byte halo exchanges per sweep.  Default `--scaling weak`: the sequence
+grows with the job (N x 100k poses through the same 10k-landmark field; every GPU owns a
+100k-pose block, i.e. the per-GPU work is the N = 1 workload).  `--scaling strong` shards the
+fixed 100k-pose sequence instead (BASELINE.json configs[4]); one sweep of it is under 1 ms on one
+GPU, so that mode is bounded by the serial Nelder-Mead chain and collective latency (DESIGN.md
+section 6).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with the two extra objects
 `roofline` (dominant kernel, measured with HIP events on the launch stream) and
@@ -115,6 +120,9 @@ def main():
     ap.add_argument("--workload", default="S2", help="S2 (BASELINE metric config), S1, tiny")
     ap.add_argument("--cpu-poses", type=int, default=-1, help="prefix length of the CPU baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = the sequence has N x the workload's poses (fixed work per GPU); "
+                         "strong = the workload's sequence split N ways")
     ap.add_argument("--force-sharded", action="store_true",
                     help="drive even a 1-rank run through the sharded path (torch.distributed + RCCL all-gathers)")
     args = ap.parse_args()
@@ -139,7 +147,8 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    T, K, B = WORKLOADS[args.workload]
+    T1, K, B = WORKLOADS[args.workload]
+    T = T1 * world if args.scaling == "weak" else T1   # poses of the whole (sharded) sequence
     blk = (T + world - 1) // world
     t_begin, t_end = min(rank * blk, T), min((rank + 1) * blk, T)
     t0 = time.perf_counter()
@@ -249,15 +258,20 @@ def main():
         Kt = st["entries"] / max(eng.nloc, 1)
         sweep_bytes = survey_bytes_per_pose(B, Kt, K, T) * (T - 1)
         roof["sweep_algorithmic_GBps"] = round(sweep_bytes / (ms_per_step * 1e-3) / 1e9, 2)
-        roof["sweep_frac_of_hbm_peak"] = round(roof["sweep_algorithmic_GBps"] / HBM_PEAK_GBS, 5)
+        roof["sweep_frac_of_hbm_peak"] = round(roof["sweep_algorithmic_GBps"] / (HBM_PEAK_GBS * world), 5)
 
     out = {
         "metric": "ICM pose-updates/sec (full sweep)", "value": round(value, 1), "unit": "pose-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: synthetic %d poses / %d landmarks / %d beams, red-black ICM sweep" % (args.workload, T, K, B),
-                   "schedule": schedule, "poses": T, "landmarks": K, "beams": B, "kept_beams": st["kept_beams"] if world == 1 else None,
-                   "parallelism": "pose-shard x%d" % world},
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": ("%s: synthetic %d poses / %d landmarks / %d beams, red-black ICM sweep" % (args.workload, T, K, B))
+                               + ("" if world == 1 else
+                                  (" -- ONE sequence of %d x %d poses, a %d-pose block per GPU" % (world, T1, blk) if args.scaling == "weak"
+                                   else " -- the %d-pose sequence split into %d-pose blocks" % (T, blk))),
+                   "schedule": schedule, "poses": T, "poses_per_gpu": blk, "landmarks": K, "beams": B,
+                   "kept_beams": st["kept_beams"] if world == 1 else None,
+                   "parallelism": "pose-shard x%d" % world,
+                   "collectives_per_sweep": 0 if not sharded else "1 all-gather of [3L+8] f64 statistics + 2 halo all-gathers of 48 B per rank"},
         "setup_s": {"generate": round(t_gen, 2), "upload_and_prefilter": round(t_upload, 2)},
     }
     if roof is not None:

@@ -10,12 +10,16 @@ Per sweep:
   2. ONE all-gather of the [3L+8] statistics: every rank gets the total (new map) and the
      exclusive prefix over lower ranks (state of each running mean at its first pose)
   3. targets, then the odd poses of the shard                                 [no comm]
-  4. all-gather of the pose blocks (neighbours' boundary poses for the even half)
-  5. the even poses, all-gather of the pose blocks
+  4. halo exchange: a solve reads only the poses t-1 and t+1, so a shard needs one pose from
+     each neighbour -- every rank contributes its first and last pose (48 B) to one tiny
+     all-gather and copies the two it needs next to its block
+  5. the even poses, halo exchange again (the next sweep's odd half reads them)
   6. Mapa.filtrar, replicated (deterministic) on every rank
 
-The payloads are tiny (240 KB of statistics per rank at L = 10k, 2.4 MB of poses), so the
-collectives are latency-bound; xGMI link bandwidth is irrelevant here.
+The pose blocks themselves are gathered only when the caller asks for the state
+(`get_state`), not per sweep.  The payloads are tiny (240 KB of statistics per rank at
+L = 10k, 48 B of halo), so the collectives are latency-bound; xGMI link bandwidth is
+irrelevant here.
 """
 import numpy as np
 
@@ -51,6 +55,25 @@ class ShardedSweep:
             engine.bind_exchange(stats.data_ptr(), rank, world)
             engine.bind_pose_buffer(poses.data_ptr())
         self.comm = comm if comm is not None else TorchComm()
+        # halo bookkeeping: rows (first pose, last pose) of every rank; which of them this rank
+        # needs (the last pose of the rank below, the first pose of the rank above; only trailing
+        # ranks can be empty, and an empty rank needs nothing)
+        a, b = self.parts[rank]
+        self.own = (a, b)
+        P = self.poses.view(-1, 3)
+        idev = P.device
+        self.halo_all = torch.zeros(world * 2, 3, dtype=torch.float64, device=idev)
+        last = max(b - 1, a) if b > a else 0
+        self.edge_idx = torch.tensor([a if b > a else 0, last], dtype=torch.long, device=idev)
+        src, dst = [], []
+        if b > a and a > 0:
+            src.append(2 * (rank - 1) + 1)
+            dst.append(a - 1)
+        if b > a and b < T:
+            src.append(2 * (rank + 1))
+            dst.append(b)
+        self.halo_src = torch.tensor(src, dtype=torch.long, device=idev)
+        self.halo_dst = torch.tensor(dst, dtype=torch.long, device=idev)
 
     def set_state(self, mapa_viejo, x, x0, lact=None):
         self.eng.set_state(mapa_viejo, x, x0, lact)
@@ -63,12 +86,14 @@ class ShardedSweep:
         self.comm.all_gather(self.stats, r, self.stride)
         e.sweep_targets()
         e.sweep_solve("redblack", 1)
-        self.comm.all_gather(self.poses, r, self.blk * 3)
+        self.comm.halo(self)
         e.sweep_solve("redblack", 0)
-        self.comm.all_gather(self.poses, r, self.blk * 3)
+        self.comm.halo(self)
         e.sweep_finish()
 
     def get_state(self):
+        """(x, map, counts, K) of the whole sequence: gathers the pose blocks first."""
+        self.comm.all_gather(self.poses, self.rank, self.blk * 3)
         return self.eng.get_state()
 
 
@@ -83,12 +108,22 @@ class TorchComm:
         mine = buf[rank * count:(rank + 1) * count].clone()
         self.dist.all_gather_into_tensor(buf, mine, group=self.group)
 
+    def halo(self, sw):
+        P = sw.poses.view(-1, 3)
+        edges = P.index_select(0, sw.edge_idx)                       # (2,3): my first and last pose
+        self.dist.all_gather_into_tensor(sw.halo_all, edges, group=self.group)
+        if sw.halo_dst.numel():
+            P.index_copy_(0, sw.halo_dst, sw.halo_all.index_select(0, sw.halo_src))
+
 
 class NoComm:
     """Ranks living in one process on one GPU and bound to the SAME buffers: every rank's
     slot is already visible to the others."""
 
     def all_gather(self, buf, rank, count):
+        pass
+
+    def halo(self, sw):
         pass
 
 

@@ -37,7 +37,9 @@ def landmarks(K, rng):
 
 def trajectory(T, n_side, rng):
     """True poses (3,T) and controls (2,T): lanes along grid corridors joined by
-    semicircles outside the field, with a gentle sinusoidal meander."""
+    semicircles outside the field, with a gentle sinusoidal meander.  The lane pitch shrinks
+    with T so that one pass covers the field; once the pitch is down to one grid row, a still
+    longer sequence reverses at the field's edge and sweeps back over it."""
     side = n_side * SPACING
     path_len = T * V_NOM * DT
     lanes = max(1, int(path_len // (side + 8.0)))
@@ -51,7 +53,7 @@ def trajectory(T, n_side, rng):
     turn_steps = int(round(np.pi * r / (V_NOM * DT)))
     lane_steps = int(round((side + 6.0) / (V_NOM * DT)))
     t = 0
-    direction = 1
+    row, heading, sense = 0, 1, 1   # lane's grid row; +1 east / -1 west; +1 field-upwards / -1 back down
     while t < T - 1:
         e = min(t + lane_steps, T - 1)
         # meander: whole cosine periods of yaw rate per lane, so the heading swings by
@@ -62,8 +64,12 @@ def trajectory(T, n_side, rng):
         if t >= T - 1:
             break
         e = min(t + turn_steps, T - 1)
-        w[t:e] = direction * (np.pi / (turn_steps * DT))
-        direction = -direction
+        # a sequence longer than one coverage of the field comes back down over it
+        if not 0 <= row + sense * rows_per_lane <= n_side - 1:
+            sense = -sense
+        row += sense * rows_per_lane
+        w[t:e] = sense * heading * (np.pi / (turn_steps * DT))
+        heading = -heading
         t = e
     for k in range(T - 1):
         th = x[2, k]

@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from util import Cfg, ROOT, dataset, gold
@@ -39,11 +40,13 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_ranks_gloo_match_unsharded_oracle(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_gloo_match_unsharded_oracle(tmp_path, world):
+    """world 2: one shard boundary; world 3: an interior rank with a halo on both sides (the
+    pose blocks are NOT exchanged per sweep, only the boundary poses are)."""
     from oracle import icm_oracle as o
-    world = 2
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_worker, args=(world, 29533, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 29533 + world, out), nprocs=world, join=True)
     zz, odo, u = dataset()
     zz, odo, u = zz[:, :T_SUB], odo[:, :T_SUB], u[:, :T_SUB]
     init = gold("init_pass.npz")
@@ -53,10 +56,12 @@ def test_two_ranks_gloo_match_unsharded_oracle(tmp_path):
     mv = init["map_init"].copy()
     for _ in range(SWEEPS):
         mv, x = o.sweep(ocfg, st, zz, u, odo, odo[:, 0], mv, x, schedule="redblack")
-    r0, r1 = np.load(out % 0), np.load(out % 1)
-    for r in (r0, r1):
+    res = [np.load(out % r) for r in range(world)]
+    r0 = res[0]
+    for r in res:
         assert int(r["K"]) == mv.shape[1]
         assert np.abs(r["m"] - mv).max() <= 1e-12     # sum/n vs the reference's recurrence
         assert np.abs(r["x"] - x).max() <= 1e-9
         assert np.array_equal(r["c"], st.cant_obs_i)
-    assert np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["m"], r1["m"])   # replicas agree
+    for r1 in res[1:]:
+        assert np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["m"], r1["m"])   # replicas agree
