@@ -26,11 +26,11 @@ std::string g_create_err;
 
 enum KernelId {
     KID_PREFILTER = 0, KID_SCAN, KID_ASSOC_BRUTE, KID_ASSOC_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_TOTALS,
-    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_FILTRAR, KID_COUNT
+    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_FILTRAR, KID_NEIGH, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_scan", "k_associate_brute", "k_assoc_group", "k_compact",
                                        "radix_sort_pairs", "k_lm_bounds", "k_lm_scan_totals", "k_stats_prefix",
-                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_filtrar_grid"};
+                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_filtrar_grid", "k_neigh_table"};
 
 template <class T>
 struct DevBuf {
@@ -84,6 +84,8 @@ struct icm_handle {
     DevBuf<int> g_cell, fl_cid, fl_cell_cnt, fl_cell_fill, fl_info;
     DevBuf<LmRec> g_lm, fl_tbl;
     DevBuf<GridParams> gpar;
+    DevBuf<NeighRec> g_nb;   // per-cell 3x3 neighbourhood records (k_neigh_table)
+    int max_cells = 0;
     DevBuf<double> fl_px, fl_py, fl_pc, counts_new;
     bool h_map_valid = true, gpu_filtrar = true;
     std::vector<LmRec> h_lm;
@@ -224,7 +226,7 @@ int icm_destroy(icm_handle* h) {
     DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->label, &h->bloc, &h->st_label, &h->st_k,
                          &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags, &h->scan_tot};
     for (auto* b : di) b->release();
-    h->g_lm.release(); h->fl_tbl.release(); h->gpar.release();
+    h->g_lm.release(); h->fl_tbl.release(); h->gpar.release(); h->g_nb.release();
     h->fl_cid.release(); h->fl_cell_cnt.release(); h->fl_cell_fill.release(); h->fl_info.release();
     h->fl_px.release(); h->fl_py.release(); h->fl_pc.release(); h->counts_new.release();
     h->e_b.release(); h->e_wr.release(); h->tgt.release(); h->e_w.release();
@@ -326,6 +328,8 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->counts_new.reserve(L));
     HIPCHK(h, h->mapx.reserve(L)); HIPCHK(h, h->mapy.reserve(L));
     HIPCHK(h, h->g_cell.reserve(8 * L + 4096 + 2));
+    h->max_cells = (int)(8 * L + 4096);   // bound of both grid builders (build_grid, block_build_grid)
+    HIPCHK(h, h->g_nb.reserve((size_t)h->max_cells));
     size_t tmp_bytes = 0;
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, nz, 0, 32, h->stream));
     HIPCHK(h, h->sort_tmp.reserve(tmp_bytes + 256));
@@ -371,6 +375,9 @@ static int upload_map(icm_handle* h) {
     }
     GridParams gp{g.gx0, g.gy0, g.inv, g.nx, g.ny};
     HIPCHK(h, hipMemcpyAsync(h->gpar.p, &gp, sizeof(gp), hipMemcpyHostToDevice, h->stream));
+    if ((int64_t)g.nx * g.ny > (int64_t)h->max_cells) FAIL(h, ICM_ERR_CAPACITY, "upload_map: search grid larger than the neighbourhood table");
+    TIMED(h, KID_NEIGH, (k_neigh_table<<<nblocks_threads((int64_t)g.nx * g.ny), kBlock, 0, h->stream>>>(GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, nullptr}, h->g_nb.p, h->max_cells)));
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors are reused
     h->h_map_valid = true;
     return ICM_OK;
@@ -462,7 +469,7 @@ int icm_sweep_local(icm_handle* h) {
     const int km = (int)std::min(h->K, h->lact);
     const int nbw = nblocks_waves(nloc);
     HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
-    GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p};
+    GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p};
     const bool dbg = h->debug || h->per_beam;
     h->assoc_kept = dbg;
 #define ASSOC_GROUP(PRE, DBG, HS)                                                                                  \
@@ -558,10 +565,13 @@ int icm_sweep_targets(icm_handle* h) {
         fa.gpar = h->gpar.p; fa.g_cell = h->g_cell.p; fa.g_lm = h->g_lm.p; fa.info = h->fl_info.p;
         if (h->timing) {  // serialised on the main stream so that the events bracket it
             TIMED(h, KID_FILTRAR, (k_filtrar_grid<<<1, kFB, 0, h->stream>>>(fa)));
+            TIMED(h, KID_NEIGH, (k_neigh_table<<<nblocks_threads(h->max_cells), kBlock, 0, h->stream>>>(GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, nullptr}, h->g_nb.p, h->max_cells)));
             HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
         } else {
             k_filtrar_grid<<<1, kFB, 0, h->copy_stream>>>(fa);
+            // the grid's size is only known on the device: one thread per cell of the capacity
+            k_neigh_table<<<nblocks_threads(h->max_cells), kBlock, 0, h->copy_stream>>>(GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, nullptr}, h->g_nb.p, h->max_cells);
         }
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));

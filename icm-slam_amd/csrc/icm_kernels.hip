@@ -288,10 +288,26 @@ struct GridParams {  // device resident: written by the host (icm_set_state) or 
     int nx, ny;
 };
 
+// Everything a beam landing in one cell can be matched to: the landmarks of the cell's 3x3
+// neighbourhood, inline, in the order the range walk below visits them.  One aligned 128-byte
+// record = ONE memory round trip per beam instead of the dependent chain cell_start ->
+// ranges -> records.  Unused slots hold x = +inf (squared distance +inf, never the nearest);
+// n > kNeighCap sends the beam down the range walk.
+constexpr int kNeighCap = 4;
+struct __attribute__((aligned(128))) NeighRec {
+    double x[kNeighCap];
+    double y[kNeighCap];
+    int id[kNeighCap];
+    int n;
+    int pad[11];
+};
+static_assert(sizeof(NeighRec) == 128, "NeighRec is one 128-byte line");
+
 struct GridView {
     const GridParams* __restrict__ par;
     const int* __restrict__ cell_start;
     const LmRec* __restrict__ lm;
+    const NeighRec* __restrict__ nb;
 };
 
 __device__ __forceinline__ int grid_cell(double v, double g0, double inv, int n) {
@@ -318,9 +334,8 @@ __device__ __forceinline__ void pose_of(const double* __restrict__ x, const doub
 //     ulps; that case (detected from the runner-up) is re-ranked exactly on sqrt;
 //   * d > thr  <=>  s > thr2, with thr2 = the largest double whose correctly rounded sqrt is
 //     <= thr (computed on the host), so the gate needs no sqrt either.
-__device__ __forceinline__ int assoc_grid(const GridView& g, const GridParams& gp, double wx, double wy, double thr,
-                                          double thr2) {
-    const int cx = grid_cell(wx, gp.gx0, gp.inv, gp.nx), cy = grid_cell(wy, gp.gy0, gp.inv, gp.ny);
+__device__ __noinline__ int assoc_grid_walk(const GridView& g, const GridParams& gp, int cx, int cy, double wx, double wy,
+                                            double thr, double thr2) {
     const int c0 = max(cx - 1, 0), c1 = min(cx + 1, gp.nx - 1);
     const int r0 = max(cy - 1, 0), r2 = min(cy + 1, gp.ny - 1);
     // rows r0, cy, r2 (clamped rows may coincide: count each distinct row once)
@@ -359,6 +374,77 @@ __device__ __forceinline__ int assoc_grid(const GridView& g, const GridParams& g
         return (bid >= 0 && !(db > thr)) ? bid : -1;
     }
     return (bid >= 0 && !(best > thr2)) ? bid : -1;
+}
+
+// The same search through the cell's inline neighbourhood record (the common case: at most
+// kNeighCap candidates).  Same candidates in the same order as the range walk, so the same
+// winner; near ties and crowded cells take the walk.
+__device__ __forceinline__ int assoc_grid(const GridView& g, const GridParams& gp, double wx, double wy, double thr,
+                                          double thr2) {
+    const int cx = grid_cell(wx, gp.gx0, gp.inv, gp.nx), cy = grid_cell(wy, gp.gy0, gp.inv, gp.ny);
+    const NeighRec* __restrict__ r = g.nb + ((size_t)cy * gp.nx + cx);
+    const double4 xa = *reinterpret_cast<const double4*>(r->x), ya = *reinterpret_cast<const double4*>(r->y);
+    const int4 ia = *reinterpret_cast<const int4*>(r->id);
+    const int n = r->n;
+    double best = __builtin_huge_val(), second = __builtin_huge_val();
+    int bid = -1;
+#define ICM_CAND(XX, YY, ID)                       \
+    {                                              \
+        const double dx = XX - wx, dy = YY - wy;   \
+        const double sq = dx * dx + dy * dy;       \
+        if (sq < best) {                           \
+            second = best;                         \
+            best = sq;                             \
+            bid = ID;                              \
+        } else {                                   \
+            second = fmin(second, sq);             \
+        }                                          \
+    }
+    ICM_CAND(xa.x, ya.x, ia.x)
+    ICM_CAND(xa.y, ya.y, ia.y)
+    ICM_CAND(xa.z, ya.z, ia.z)
+    ICM_CAND(xa.w, ya.w, ia.w)
+#undef ICM_CAND
+    if (n == 0) return -1;
+    if (n > kNeighCap || second <= best * (1.0 + 1e-15)) return assoc_grid_walk(g, gp, cx, cy, wx, wy, thr, thr2);
+    return (bid >= 0 && !(best > thr2)) ? bid : -1;
+}
+
+// Fills the neighbourhood records of every cell of the current grid (one thread per cell;
+// launched with the cell CAPACITY because the grid's size may only be known on the device).
+__global__ __launch_bounds__(kBlock) void k_neigh_table(GridView g, NeighRec* __restrict__ out, int max_cells) {
+    const GridParams gp = *g.par;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= gp.nx * gp.ny || c >= max_cells) return;
+    const int cy = c / gp.nx, cx = c - cy * gp.nx;
+    const int c0 = max(cx - 1, 0), c1 = min(cx + 1, gp.nx - 1);
+    const int r0 = max(cy - 1, 0), r2 = min(cy + 1, gp.ny - 1);
+    const int pa = g.cell_start[r0 * gp.nx + c0], na = g.cell_start[r0 * gp.nx + c1 + 1] - pa;
+    const int pb = g.cell_start[cy * gp.nx + c0], nb = cy != r0 ? g.cell_start[cy * gp.nx + c1 + 1] - pb : 0;
+    const int pc = g.cell_start[r2 * gp.nx + c0], nc = r2 != cy ? g.cell_start[r2 * gp.nx + c1 + 1] - pc : 0;
+    const int n = na + nb + nc;
+    NeighRec rec;
+    for (int i = 0; i < kNeighCap; ++i) {
+        rec.x[i] = __builtin_huge_val();
+        rec.y[i] = 0.0;
+        rec.id[i] = -1;
+    }
+    for (int i = 0; i < kNeighCap; ++i) {  // (a fixed-trip loop: rec stays in registers)
+        if (i < n) {
+            const int p = i < na ? pa + i : (i < na + nb ? pb + (i - na) : pc + (i - na - nb));
+            const LmRec q = g.lm[p];
+            rec.x[i] = q.x;
+            rec.y[i] = q.y;
+            rec.id[i] = q.id;
+        }
+    }
+    rec.n = n;
+    double4* o = reinterpret_cast<double4*>(out + c);
+    o[0] = make_double4(rec.x[0], rec.x[1], rec.x[2], rec.x[3]);
+    o[1] = make_double4(rec.y[0], rec.y[1], rec.y[2], rec.y[3]);
+    int4* oi = reinterpret_cast<int4*>(out[c].id);
+    oi[0] = make_int4(rec.id[0], rec.id[1], rec.id[2], rec.id[3]);
+    out[c].n = n;
 }
 
 // Brute-force form of the same association (all K landmarks, table tiled through LDS): the
@@ -455,6 +541,9 @@ __device__ __forceinline__ void seg_step(bool take, double& ax, double& ay) {
 // HS = 128 keeps the kernel at 14 KB of LDS and 64 VGPRs = 8 waves per SIMD (the kernel waits
 // on memory 2/3 of the time, so occupancy matters); a scan that overflows it makes the host
 // relaunch the sweep's phase A with HS = 256.
+#ifndef ICM_ASSOC_WPE
+#define ICM_ASSOC_WPE 8
+#endif
 template <int HS>
 struct PoseTable {
     int key[HS];
@@ -465,7 +554,7 @@ struct PoseTable {
 };
 
 template <bool PRELABEL, bool DEBUG, int HS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? 8 : 4, HS == 128 ? 8 : 5)))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_ASSOC_WPE : 4, HS == 128 ? 8 : 5)))
 void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int t_begin, int nloc, const int* __restrict__ boff,
                                                         const double* __restrict__ bx, const double* __restrict__ by,
@@ -502,15 +591,26 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     int nent = 0;
     bool overflow = false;
     __builtin_amdgcn_wave_barrier();
+    // the beams of chunk c+1 are requested before chunk c is searched (one round trip hidden)
+    double nbx = 0.0, nby = 0.0;
+    if (j0 + lane < j1) {
+        nbx = bx[j0 + lane];
+        nby = by[j0 + lane];
+    }
     for (int base = j0; base < j1 && !overflow; base += kWave) {
         const int j = base + lane;
         const bool valid = j < j1;
         const int cn = min(kWave, j1 - base);
         int lab = -2;
-        double bxx = 0.0, byy = 0.0;
+        const double bxx = nbx, byy = nby;
+        if (j + kWave < j1) {
+            nbx = bx[j + kWave];
+            nby = by[j + kWave];
+        } else {
+            nbx = 0.0;
+            nby = 0.0;
+        }
         if (valid) {
-            bxx = bx[j];
-            byy = by[j];
             if (PRELABEL) {
                 lab = label[j];
             } else {
