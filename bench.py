@@ -41,11 +41,20 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 FP64 FMA lanes x 2 x 2.4 
 FLOP_PER_ENERGY_EVAL = 180    # moment-form fun_xn: trig 24, observation quadratic form 67, priors 87
 
 
-def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch):
+def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True):
     """Compulsory HBM bytes ONE launch of `kernel` moves: every array
     the kernel must read or write once, no re-reads.  nnz = kept beams, E = (pose, landmark)
-    entries, nloc = poses of the shard, L = landmark capacity."""
+    entries, nloc = poses of the shard, L = landmark capacity; hier = the hierarchical entry
+    pipeline ran (k_pose_moments then reads the staged entries and the prefixes itself)."""
+    nchunks = (nloc + 63) // 64
+    group = (nchunks + 63) // 64
+    nsuper = (nchunks + group - 1) // max(group, 1)
     per_sweep = {
+        # staged entry in (label 4, k 4, sum bx 8, sum by 8); prefix (24) + record id (4) out;
+        # per pose: offsets 16 + pose 24; per chunk: 256 record labels
+        "k_chunk_l1": E * 24 + E * 28 + nloc * 40 + nchunks * 256 * 4,
+        # dense [superchunks x L] matrix of (sx, sy, n): read once, written once
+        "k_lm_l3": 2 * 3 * 8 * nsuper * L + L * 24,
         # read body x,y of every kept beam (16 B) + pose; write one staged entry
         # (label 4, k 4, sum bx 8, sum by 8) per distinct landmark of the scan; counts/flags
         "k_assoc_group": nnz * 16 + E * 24 + nloc * (24 + 8 + 8),
@@ -61,7 +70,8 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch):
         "k_lm_scan": E * (4 + 32 + 16) + L * (8 + 24),
         "k_beam_targets": nnz * (4 + 16) + E * 16,
         # per entry: k 4, rotated mean 16, target 16; per pose: pose 24, scatter 24, 17 moments out
-        "k_pose_moments": E * 36 + nloc * (24 + 24 + 136 + 8),
+        # hierarchical pipeline: staged k + sums 20, prefix 24, record id 4, record prefix 24 (L2-resident gather)
+        "k_pose_moments": (E * (20 + 24 + 4 + 24) if hier else E * 36) + nloc * (24 + 24 + 136 + 8),
         # both colours together, per pose: 17 moments, own + 2 neighbour poses, odometry 72, u 32, pose out 24
         "k_solve": nloc * (136 + 72 + 72 + 32 + 24 + 8),
         "k_scan": nloc * 16,
@@ -201,23 +211,25 @@ def main():
             step()
         fence()
         kt = {k: v for k, v in eng.kernel_times().items() if v[1] > 0 and k != "k_prefilter"}
+        hier = eng.entry_path() == "hier"
         eng.enable_timing(False)
         # k_filtrar_grid is one workgroup on a side stream, concurrent with the solves: not on
         # the critical path and not a bandwidth kernel, so it is never the roofline subject
-        dom = max((k for k in kt if k != "k_filtrar_grid"), key=lambda k: kt[k][0])
+        side = ("k_filtrar_grid", "k_neigh_table")   # side stream, under the solves
+        dom = max((k for k in kt if k not in side), key=lambda k: kt[k][0])
         per_kernel = {}
         for k, (ms_k, n_k) in kt.items():
-            ab = algorithmic_bytes(k, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof)
+            ab = algorithmic_bytes(k, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof, hier)
             per_kernel[k] = {"ms_per_launch": round(ms_k / n_k, 4), "launches_per_sweep": n_k / nroof,
                              "GBps": round(ab / (ms_k / n_k * 1e-3) / 1e9, 1) if ab else None}
         ms, n = kt[dom]
         avg_ms = ms / n
         nl = n / nroof
-        abytes = algorithmic_bytes(dom, st["kept_beams"], st["entries"], eng.nloc, eng.L, nl)
+        abytes = algorithmic_bytes(dom, st["kept_beams"], st["entries"], eng.nloc, eng.L, nl, hier)
         ach = abytes / (avg_ms * 1e-3) / 1e9
         def hbm_roof(kname):
             ms_k, n_k = kt[kname]
-            ab = algorithmic_bytes(kname, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof)
+            ab = algorithmic_bytes(kname, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof, hier)
             a_gbs = ab / (ms_k / n_k * 1e-3) / 1e9
             return {"bound": "hbm", "kernel": kname, "achieved": round(a_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(a_gbs / HBM_PEAK_GBS, 5), "traffic": traffic_of(kname),
@@ -231,16 +243,19 @@ def main():
             except Exception:
                 return None
 
-        stream_kernel = max((k for k in kt if k not in ("k_filtrar_grid", "k_solve")), key=lambda k: kt[k][0])
+        stream_kernel = max((k for k in kt if k not in side + ("k_solve",)), key=lambda k: kt[k][0])
         if dom == "k_solve":
             # the solves are not a bandwidth kernel: one lane per pose runs ~85 dependent energy
             # evaluations from registers.  Their roofline is the FP64 vector rate; the flops are the
             # measured number of energy evaluations x the flops of one evaluation.
             eng.set_debug(True)
+            if hier:
+                eng.set_entry_path("hier")   # (debug alone would select the sort-based pipeline)
             step()
             fence()
             nfev = float(eng.solve_diag()[:, 2].sum())
             eng.set_debug(False)
+            eng.set_entry_path("auto")
             flops = nfev * FLOP_PER_ENERGY_EVAL / nl
             tfl = flops / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "valu_fp64", "kernel": dom, "achieved": round(tfl, 3), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -270,7 +285,7 @@ def main():
                                    else " -- the %d-pose sequence split into %d-pose blocks" % (T, blk))),
                    "schedule": schedule, "poses": T, "poses_per_gpu": blk, "landmarks": K, "beams": B,
                    "kept_beams": st["kept_beams"] if world == 1 else None,
-                   "parallelism": "pose-shard x%d" % world,
+                   "parallelism": "pose-shard x%d" % world, "entry_pipeline": eng.entry_path(),
                    "collectives_per_sweep": 0 if not sharded else "1 all-gather of [3L+8] f64 statistics + 2 halo all-gathers of 48 B per rank"},
         "setup_s": {"generate": round(t_gen, 2), "upload_and_prefilter": round(t_upload, 2)},
     }

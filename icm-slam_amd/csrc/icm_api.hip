@@ -26,11 +26,12 @@ std::string g_create_err;
 
 enum KernelId {
     KID_PREFILTER = 0, KID_SCAN, KID_ASSOC_BRUTE, KID_ASSOC_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_TOTALS,
-    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_FILTRAR, KID_NEIGH, KID_COUNT
+    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_FILTRAR, KID_NEIGH, KID_CHUNK_L1, KID_CHUNK_L2, KID_LM_L3, KID_REC_PUSH, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_scan", "k_associate_brute", "k_assoc_group", "k_compact",
                                        "radix_sort_pairs", "k_lm_bounds", "k_lm_scan_totals", "k_stats_prefix",
-                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_filtrar_grid", "k_neigh_table"};
+                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_filtrar_grid", "k_neigh_table",
+                                       "k_chunk_l1", "k_chunk_l2", "k_lm_l3", "k_rec_push"};
 
 template <class T>
 struct DevBuf {
@@ -99,6 +100,13 @@ struct icm_handle {
     DevBuf<EntW> e_w;
     DevBuf<double> stats_own, off_sx, off_sy, off_n, y_raw, cnt_raw, diag;
     DevBuf<unsigned char> sort_tmp;
+    // hierarchical running sums (k_chunk_l1 .. k_rec_push): records = chunks x kT1 slots
+    DevBuf<int> rec_label;
+    DevBuf<double> rec_s, rec_off, ms;   // [3][nrec], [3][nrec], [3][nsuper][L]
+    int nchunks = 0, chunk_group = 1, nsuper = 0;
+    int entry_path = -1;     // -1 automatic, 0 sort-based pipeline, 1 hierarchical (falls back when a table overflows)
+    bool hier_ok = true;     // cleared by an overflow until the next icm_set_state
+    int path_used = 0;       // pipeline of the last sweep: 0 sort-based, 1 hierarchical
     double* stats_all = nullptr;
     int rank = 0, world = 1;
     int64_t E = 0, n_new_loc = 0, lact_raw = 0;
@@ -233,6 +241,7 @@ int icm_destroy(icm_handle* h) {
     h->e_key.release();
     h->skey.release();
     h->sort_tmp.release();
+    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release();
     if (h->pin_i) (void)hipHostFree(h->pin_i);
     if (h->pin_d) (void)hipHostFree(h->pin_d);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -312,9 +321,9 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->label.reserve(nz)); HIPCHK(h, h->bloc.reserve(nz)); HIPCHK(h, h->st_label.reserve(nz));
     HIPCHK(h, h->st_k.reserve(nz)); HIPCHK(h, h->st_sx.reserve(nz)); HIPCHK(h, h->st_sy.reserve(nz));
     HIPCHK(h, h->btx.reserve(nz)); HIPCHK(h, h->bty.reserve(nz));
-    HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz));
+    HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz + kWave));
     HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_b.reserve(nz));
-    HIPCHK(h, h->e_w.reserve(nz)); HIPCHK(h, h->e_wr.reserve(nz)); HIPCHK(h, h->tgt.reserve(nz));
+    HIPCHK(h, h->e_w.reserve(nz + kWave)); HIPCHK(h, h->e_wr.reserve(nz)); HIPCHK(h, h->tgt.reserve(nz));
     HIPCHK(h, h->scan_tot.reserve(2 * ((size_t)nloc / kScanTile + 2)));
     HIPCHK(h, h->nent.reserve((size_t)nloc + 1)); HIPCHK(h, h->isnew.reserve((size_t)nloc + 1));
     HIPCHK(h, h->ent_off.reserve((size_t)nloc + 1)); HIPCHK(h, h->new_rank.reserve((size_t)nloc + 1));
@@ -328,6 +337,14 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->counts_new.reserve(L));
     HIPCHK(h, h->mapx.reserve(L)); HIPCHK(h, h->mapy.reserve(L));
     HIPCHK(h, h->g_cell.reserve(8 * L + 4096 + 2));
+    h->nchunks = (nloc + kCH - 1) / kCH;
+    h->chunk_group = (h->nchunks + kMaxSuper - 1) / kMaxSuper;
+    h->nsuper = (h->nchunks + h->chunk_group - 1) / h->chunk_group;
+    {
+        const size_t nrec = (size_t)h->nchunks * kT1;
+        HIPCHK(h, h->rec_label.reserve(nrec)); HIPCHK(h, h->rec_s.reserve(3 * nrec)); HIPCHK(h, h->rec_off.reserve(3 * nrec));
+        HIPCHK(h, h->ms.reserve(3 * (size_t)h->nsuper * L));
+    }
     h->max_cells = (int)(8 * L + 4096);   // bound of both grid builders (build_grid, block_build_grid)
     HIPCHK(h, h->g_nb.reserve((size_t)h->max_cells));
     size_t tmp_bytes = 0;
@@ -413,6 +430,7 @@ int icm_set_state(icm_handle* h, const double* x, const double* x0, const double
     int rc = upload_map(h);
     if (rc) return rc;
     h->have_state = true;
+    h->hier_ok = true;
     return ICM_OK;
 }
 
@@ -480,6 +498,15 @@ int icm_sweep_local(icm_handle* h) {
     if (h->brute)
         TIMED(h, KID_ASSOC_BRUTE, (k_associate_brute<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->mapx.p, h->mapy.p, km, h->cfg.dist_thr, h->label.p)));
     const int ntiles = (nloc + kScanTile - 1) / kScanTile;
+    // Entry pipeline: hierarchical running sums (no sort) for the moment-form solves; the
+    // sort-based pipeline when the per-beam / per-entry cross-check forms or the association
+    // dump need its per-entry arrays, when asked for, or after a table overflow.
+    bool hier = h->entry_path != 0 && h->hier_ok && h->form == 0 && (!dbg || h->entry_path == 1);
+    const int nrec = h->nchunks * kT1;
+    double* const pre = reinterpret_cast<double*>(h->e_w.p);   // [3][nnz] (the sort-based path's record buffer)
+    const size_t nzs = (size_t)std::max<int64_t>(h->nnz, 1) + kWave;   // + the dump row of k_chunk_l1
+    double* const ms = h->ms.p;
+    const size_t msn = (size_t)h->nsuper * (size_t)L;
     for (;;) {
         if (h->brute) {
             if (dbg) ASSOC_GROUP_HS(true, true); else ASSOC_GROUP_HS(true, false);
@@ -488,9 +515,21 @@ int icm_sweep_local(icm_handle* h) {
         }
         TIMED(h, KID_SCAN, (k_scan_tiles<<<ntiles, kBlock, 0, h->stream>>>(h->nent.p, h->isnew.p, h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc)));
         TIMED(h, KID_SCAN, (k_scan_fix<<<ntiles, kBlock, 0, h->stream>>>(h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc, ntiles)));
+        if (hier) {  // launched before the host looks at the counts: one synchronisation per sweep
+            TIMED(h, KID_CHUNK_L1, (k_chunk_l1<<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(
+                h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->boff.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0,
+                h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, pre + 2 * nzs, h->e_val.p,
+                h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave)));
+            HIPCHK(h, hipMemsetAsync(ms, 0, 3 * msn * sizeof(double), h->stream));
+            TIMED(h, KID_CHUNK_L2, (k_chunk_l2<<<h->nsuper, kT1, 0, h->stream>>>(
+                h->nchunks, h->chunk_group, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
+                h->rec_off.p, h->rec_off.p + nrec, h->rec_off.p + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->flags.p)));
+            double* stats_mine = h->world > 1 ? h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h) : nullptr;
+            TIMED(h, KID_LM_L3, (k_lm_l3<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, h->new_rank.p + nloc, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p)));
+        }
         HIPCHK(h, hipMemcpyAsync(h->pin_i, h->ent_off.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->pin_i + 1, h->new_rank.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->pin_i[2] && h->hash_slots == 128) {  // a scan with > 96 distinct landmarks: use the larger table from now on
             h->hash_slots = 256;
@@ -509,6 +548,16 @@ int icm_sweep_local(icm_handle* h) {
         FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
     const int nlab = h->lact0 + (int)h->n_new_loc;
     const int E = (int)h->E;
+    if (hier && h->pin_i[3]) {  // a chunk or superchunk table overflowed: this map is too dense for the tables
+        hier = false;
+        h->hier_ok = false;
+    }
+    h->path_used = hier ? 1 : 0;
+    if (hier) {
+        if (h->world > 1) k_set_header<<<1, 1, 0, h->stream>>>(h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h), L, (double)h->n_new_loc, 0.0);
+        HIPCHK(h, hipGetLastError());
+        return ICM_OK;
+    }
     TIMED(h, KID_COMPACT, (k_compact<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, h->e_key.p, h->e_val.p, h->e_k.p, h->form == 2 ? h->e_b.p : nullptr, h->e_w.p, h->e_wr.p, h->pose_c.p)));
     int bits = 1;
     while ((1ll << bits) < (int64_t)nlab + 1) ++bits;
@@ -533,13 +582,28 @@ int icm_sweep_targets(icm_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     const int nlab = h->lact0 + (int)h->n_new_loc;
-    if (h->world > 1) {
+    if (h->path_used == 1) {
+        const int nrec = h->nchunks * kT1;
+        const size_t msn = (size_t)h->nsuper * (size_t)L;
+        const size_t nzs = (size_t)std::max<int64_t>(h->nnz, 1) + kWave;
+        const double* pre = reinterpret_cast<const double*>(h->e_w.p);
+        double* ro = h->rec_off.p;
+        if (h->world > 1)
+            TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
+        TIMED(h, KID_REC_PUSH, (k_rec_push<<<nblocks_threads(nrec), kBlock, 0, h->stream>>>(
+            nrec, h->chunk_group, L, h->rec_label.p, h->ms.p, h->ms.p + msn, h->ms.p + 2 * msn,
+            h->world > 1 ? h->off_sx.p : nullptr, h->world > 1 ? h->off_sy.p : nullptr, h->world > 1 ? h->off_n.p : nullptr,
+            ro, ro + nrec, ro + 2 * (size_t)nrec)));
+        TIMED(h, KID_POSE_MOMENTS, (k_pose_moments_h<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(
+            h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p,
+            pre, pre + nzs, pre + 2 * nzs, h->e_val.p, ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr)));
+    } else if (h->world > 1) {
         TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
         TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, h->off_sx.p, h->off_sy.p, h->off_n.p, h->tgt.p, nullptr, nullptr, nullptr)));
     } else {
         TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, nullptr, nullptr, nullptr, h->tgt.p, nullptr, h->y_raw.p, h->cnt_raw.p)));
     }
-    if (h->form == 0)
+    if (h->form == 0 && h->path_used != 1)
         TIMED(h, KID_POSE_MOMENTS, (k_pose_moments<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->ent_off.p, h->e_k.p, h->e_wr.p, h->tgt.p, h->pose_c.p, h->pose_m.p)));
     if (h->assoc_kept)
         TIMED(h, KID_BEAM_TARGETS, (k_beam_targets<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->bloc.p, h->tgt.p, h->btx.p, h->bty.p)));
@@ -957,6 +1021,16 @@ int icm_set_solve_lanes(icm_handle* h, int mode) {
     h->solve_quad = mode;
     return ICM_OK;
 }
+
+int icm_set_entry_path(icm_handle* h, int mode) {
+    if (!h) return ICM_ERR_ARG;
+    if (mode < -1 || mode > 1) FAIL(h, ICM_ERR_ARG, "icm_set_entry_path: mode must be -1, 0 or 1");
+    h->entry_path = mode;
+    h->hier_ok = true;
+    return ICM_OK;
+}
+
+int icm_get_entry_path(const icm_handle* h) { return h ? h->path_used : ICM_ERR_ARG; }
 
 int icm_set_gpu_filtrar(icm_handle* h, int on) {
     if (!h) return ICM_ERR_ARG;

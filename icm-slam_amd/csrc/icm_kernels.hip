@@ -5,15 +5,22 @@
 //   phase A   k_assoc_group    project + gated nearest landmark + per-pose grouping: one
 //                              (pose, landmark) ENTRY per distinct label of the scan with
 //                              the count and the sums of the body / world points
+//             k_neigh_table    per-cell 3x3 neighbourhood records of the search grid
 //             k_scan_*         entry offsets, ranks of poses that create a landmark
+//   phase B/D (default) hierarchical running sums, no sort:
+//             k_chunk_l1       one wave per 64-pose chunk, poses in time order, LDS table by landmark
+//             k_chunk_l2       one workgroup per superchunk of chunks -> dense [superchunk x L] totals
+//             k_lm_l3          one thread per landmark: column prefix, landmark totals (raw map)
+//             k_rec_push       per (chunk, landmark) record: sums before the chunk
+//   phase B/D (fallback for very dense maps; per-beam / per-entry cross-check forms; debug dump):
 //             k_compact        entries -> pose-major compact records, fresh ids for new landmarks
 //             (radix sort of the entry ids by label, rocPRIM)      -> CSR by landmark
-//   phase B/D k_lm_scan        one wave per landmark: time-ordered prefix of its entries
+//             k_lm_scan        one wave per landmark: time-ordered prefix of its entries
 //                              -> running-mean target of every entry, landmark totals
 //             k_stats_prefix   totals + exclusive prefix over lower ranks (after all-gather)
 //             k_filtrar_grid   Mapa.filtrar + search grid of the refined map (one workgroup,
 //                              side stream, under the solves)
-//   phase C   k_pose_moments   14 moment sums of the pose's observation energy
+//   phase C   k_pose_moments[_h]  14 moment sums of the pose's observation energy
 //             k_solve_m_*      Nelder-Mead on the conditional energy in moment form:
 //                              ONE LANE per pose, everything in registers
 //             k_solve_* (wave per pose, per-beam / per-entry energy): cross-checks
@@ -915,6 +922,374 @@ __global__ __launch_bounds__(kBlock) void k_stats_prefix(const double* __restric
 }
 
 // ---------------------------------------------------------------------------------------
+// Phase B/D WITHOUT a sort: hierarchical running sums over time.
+//
+// The target of entry (pose t, landmark l) is the mean of l's observations through pose t
+// (SURVEY Appendix A.3/A.6 phase B): a prefix, in time, of the per-landmark sums.  Consecutive
+// poses see nearly the same landmarks, so the prefix is formed level by level instead of
+// sorting all entries by landmark:
+//   k_chunk_l1   one WAVE per chunk of kCH consecutive poses walks its poses in time order;
+//                a small LDS table keyed by landmark holds the running sums of the chunk:
+//                every entry gets its prefix inside the chunk, every (chunk, landmark) RECORD
+//                the chunk's total.  Record r = chunk * kT1 + table slot (unused slots empty).
+//   k_chunk_l2   one workgroup per SUPERCHUNK of G consecutive chunks walks its chunks in
+//                order with a larger LDS table: every record gets its prefix inside the
+//                superchunk; the superchunk's per-landmark totals go to one row of a dense
+//                [superchunks x L] matrix (at most kMaxSuper rows).
+//   k_lm_l3      one thread per landmark: exclusive prefix down its matrix column, landmark
+//                totals (= the raw map, or the rank's statistics for the exchange).
+//   k_rec_push   record prefix := (lower ranks) + matrix prefix + superchunk prefix.
+//   k_pose_moments_h then forms  target = (record prefix + entry prefix) / n  on the fly.
+// Everything streams or stays in LDS/L2: no global sort, no per-landmark gather/scatter.
+// A chunk with more than ~190 distinct landmarks, or a superchunk with more than kT2Cap,
+// raises flags[1]; the host then runs the sort-based pipeline (k_compact .. k_lm_scan), which
+// has no such limits.
+// ---------------------------------------------------------------------------------------
+constexpr int kCH = 64;          // poses per chunk (= lanes: lane p holds pose p's header)
+constexpr int kT1 = 256;         // slots of a chunk table
+constexpr int kT2 = 2048;        // slots of a superchunk table
+constexpr int kT2Cap = 1536;
+constexpr int kMaxSuper = 64;    // rows of the dense matrix
+
+struct ChunkTable {
+    int key[kT1];
+    double sx[kT1 + kWave];   // (+ one scratch slot per lane: idle lanes run the same code branch-free)
+    double sy[kT1 + kWave];
+    double sn[kT1 + kWave];
+    int used;
+};
+
+__device__ __forceinline__ int table_slot(int* key, int mask, int shift, int lab, bool& inserted) {
+    int slot = (int)(((unsigned)lab * 2654435761u) >> shift);
+    inserted = false;
+    for (;;) {
+        const int k = key[slot];
+        if (k == lab) break;
+        if (k == kEmpty) {
+            const int old = atomicCAS(&key[slot], kEmpty, lab);
+            if (old == kEmpty) {
+                inserted = true;
+                break;
+            }
+            if (old == lab) break;
+        }
+        slot = (slot + 1) & mask;
+    }
+    return slot;
+}
+
+// Value of lane `l` (wave-uniform index) in every lane: v_readlane, no LDS round trip.
+__device__ __forceinline__ int lane_bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// First 64 staged entries of kGroup consecutive poses (lane = entry), requested together.
+constexpr int kGroup = 8;
+struct EntryGroup {
+    int lab[kGroup], k[kGroup];
+    double bx[kGroup], by[kGroup];
+};
+
+__device__ __forceinline__ void load_group(EntryGroup& g, int p0, int lane, int n, int j0, const int* __restrict__ st_label,
+                                           const int* __restrict__ st_k, const double* __restrict__ st_sbx,
+                                           const double* __restrict__ st_sby) {
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+        const int np = lane_bcast(n, p0 + i), jp = lane_bcast(j0, p0 + i);
+        // every lane loads (idle lanes re-read staged entry 0): no branch around the loads, so the
+        // compiler can count them and wait for exactly the group it is about to use
+        const int j = lane < np ? jp + lane : 0;
+        const int lab = st_label[j];
+        g.lab[i] = lane < np ? lab : kEmpty;
+        g.k[i] = st_k[j];
+        g.bx[i] = st_sbx[j];
+        g.by[i] = st_sby[j];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ x, const double* __restrict__ x0,
+                                                     int t_begin, int nloc, int nchunks, const int* __restrict__ boff,
+                                                     const int* __restrict__ nent, const int* __restrict__ ent_off,
+                                                     const int* __restrict__ new_rank, int lact0,
+                                                     const int* __restrict__ st_label, const int* __restrict__ st_k,
+                                                     const double* __restrict__ st_sbx, const double* __restrict__ st_sby,
+                                                     double* __restrict__ pre_x, double* __restrict__ pre_y,
+                                                     double* __restrict__ pre_n, int* __restrict__ e_rec,
+                                                     int* __restrict__ rec_label, double* __restrict__ rec_sx,
+                                                     double* __restrict__ rec_sy, double* __restrict__ rec_n,
+                                                     int* __restrict__ flags, size_t dump) {
+    __shared__ ChunkTable tables[kWavesPerBlock];
+    const int lane = lane_id();
+    const int c = blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (c >= nchunks) return;
+    ChunkTable& T = tables[wave_in_block()];
+    for (int s = lane; s < kT1; s += kWave) {
+        T.key[s] = kEmpty;
+        T.sx[s] = 0.0;
+        T.sy[s] = 0.0;
+        T.sn[s] = 0.0;
+    }
+    if (lane == 0) T.used = 0;
+    // lane p: header of pose p of the chunk
+    const int tl = c * kCH + lane;
+    int j0 = 0, n = 0, e0 = 0, nr = 0;
+    double px = 0.0, py = 0.0, th = 0.0;
+    if (tl < nloc) {
+        j0 = boff[tl];
+        n = nent[tl];
+        e0 = ent_off[tl];
+        nr = new_rank[tl];
+        pose_of(x, x0, t_begin + tl, px, py, th);
+    }
+    if (__ballot(n > kWave) != 0ull) {  // a scan with more than 64 distinct landmarks: the lanes of this
+        for (int s = lane; s < kT1; s += kWave) rec_label[c * kT1 + s] = kEmpty;  // kernel map to entries
+        if (lane == 0) flags[1] = 1;                                               // -> sort-based path
+        return;
+    }
+    EntryGroup cur, nxt;
+    load_group(cur, 0, lane, n, j0, st_label, st_k, st_sbx, st_sby);
+    const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
+    __builtin_amdgcn_wave_barrier();
+    bool overflow = false;
+    for (int p0 = 0; p0 < kCH && !overflow; p0 += kGroup) {
+        // the next group's entries are in flight while this one is folded in
+        if (p0 + kGroup < kCH) load_group(nxt, p0 + kGroup, lane, n, j0, st_label, st_k, st_sbx, st_sby);
+        // 1. table slots of the group's entries: independent of the running sums, all at once
+        int slot[kGroup];
+        unsigned pending = 0u;   // bit i: this lane's entry of pose i has no slot yet
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) {
+            const int fresh = lact0 + lane_bcast(nr, p0 + i);
+            if (cur.lab[i] != kEmpty) {
+                if (cur.lab[i] < 0) cur.lab[i] = fresh;            // gated-out beams: one fresh landmark
+                pending |= 1u << i;
+            }
+            slot[i] = (int)(((unsigned)cur.lab[i] * 2654435761u) >> 24);
+        }
+        // the kGroup probe sequences advance together: one LDS round trip per step for all of them
+        for (int probes = 0; probes < kT1 && __ballot(pending != 0u) != 0ull; ++probes) {
+            int kv[kGroup];
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) kv[i] = T.key[slot[i]];
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) {
+                if (pending & (1u << i)) {
+                    int k = kv[i];
+                    if (k == kEmpty) {
+                        k = atomicCAS(&T.key[slot[i]], kEmpty, cur.lab[i]);
+                        if (k == kEmpty) {
+                            atomicAdd(&T.used, 1);
+                            k = cur.lab[i];
+                        }
+                    }
+                    if (k == cur.lab[i]) pending &= ~(1u << i);
+                    else slot[i] = (slot[i] + 1) & (kT1 - 1);
+                }
+            }
+        }
+        if (pending) slot[0] = -1;   // table full
+        __builtin_amdgcn_wave_barrier();
+        {
+            const bool bad = T.used > kT1 - 32 || slot[0] < 0;
+            if (__ballot(bad) != 0ull) {  // too many distinct landmarks for the table: sort-based path
+                overflow = true;
+                break;
+            }
+        }
+        // 2. the poses in time order: running sums of their landmarks
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) {
+            const int p = p0 + i;
+            const int np = lane_bcast(n, p);
+            if (np == 0) continue;
+            const int ep = lane_bcast(e0, p);
+            const double pxp = lane_bcast(px, p), pyp = lane_bcast(py, p);
+            const double ctp = lane_bcast(ct, p), stp = lane_bcast(st, p);
+            {
+                const bool act = lane < np;
+                const double kd = (double)cur.k[i], sbx = cur.bx[i], sby = cur.by[i];
+                const double rx = ctp * sbx - stp * sby, ry = stp * sbx + ctp * sby;  // R sum b
+                const double wx = kd * pxp + rx, wy = kd * pyp + ry;                  // sum of world points
+                const int sl = act ? slot[i] : kT1 + lane;   // idle lanes: scratch slots behind the table
+                // labels are distinct within a pose: no two lanes meet in a slot
+                const double ax = T.sx[sl] + wx, ay = T.sy[sl] + wy, an = T.sn[sl] + kd;
+                T.sx[sl] = ax;
+                T.sy[sl] = ay;
+                T.sn[sl] = an;
+                // idle lanes store to the dump row behind the entries (no branch around the stores either)
+                const size_t o = act ? (size_t)(ep + lane) : dump + lane;
+                pre_x[o] = ax;
+                pre_y[o] = ay;
+                pre_n[o] = an;
+                e_rec[o] = c * kT1 + sl;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        cur = nxt;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < kT1; s += kWave) {
+        const int r = c * kT1 + s;
+        const int k = overflow ? kEmpty : T.key[s];
+        rec_label[r] = k;
+        if (k != kEmpty) {
+            rec_sx[r] = T.sx[s];
+            rec_sy[r] = T.sy[s];
+            rec_n[r] = T.sn[s];
+        }
+    }
+    if (overflow && lane == 0) flags[1] = 1;
+}
+
+// Level 2: thread s of the workgroup <-> slot s of each chunk's record block.
+__global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, const int* __restrict__ rec_label,
+                                                  const double* __restrict__ rec_sx, const double* __restrict__ rec_sy,
+                                                  const double* __restrict__ rec_n, double* __restrict__ off_x,
+                                                  double* __restrict__ off_y, double* __restrict__ off_n,
+                                                  double* __restrict__ ms_x, double* __restrict__ ms_y,
+                                                  double* __restrict__ ms_n, int* __restrict__ flags) {
+    __shared__ int key[kT2];
+    __shared__ double sx[kT2], sy[kT2], sn[kT2];
+    __shared__ int used;
+    const int tid = threadIdx.x, sc = blockIdx.x;
+    for (int s = tid; s < kT2; s += kT1) {
+        key[s] = kEmpty;
+        sx[s] = 0.0;
+        sy[s] = 0.0;
+        sn[s] = 0.0;
+    }
+    if (tid == 0) used = 0;
+    __syncthreads();
+    const int c0 = sc * G, c1 = min(c0 + G, nchunks);
+    int lab_n = kEmpty;
+    double vx_n = 0.0, vy_n = 0.0, vn_n = 0.0;
+    if (c0 < c1) {
+        const size_t r = (size_t)c0 * kT1 + tid;
+        lab_n = rec_label[r];
+        vx_n = rec_sx[r];
+        vy_n = rec_sy[r];
+        vn_n = rec_n[r];
+    }
+    bool overflow = false;
+    for (int c = c0; c < c1; ++c) {
+        const int lab = lab_n;
+        const double vx = vx_n, vy = vy_n, vn = vn_n;
+        if (c + 1 < c1) {  // next chunk's records are in flight while this one is folded in
+            const size_t r = (size_t)(c + 1) * kT1 + tid;
+            lab_n = rec_label[r];
+            vx_n = rec_sx[r];
+            vy_n = rec_sy[r];
+            vn_n = rec_n[r];
+        }
+        if (lab != kEmpty) {
+            bool inserted;
+            const int slot = table_slot(key, kT2 - 1, 21, lab, inserted);
+            if (inserted) atomicAdd(&used, 1);
+            const double ox = sx[slot], oy = sy[slot], on = sn[slot];  // a landmark has one record per chunk
+            const size_t r = (size_t)c * kT1 + tid;
+            off_x[r] = ox;
+            off_y[r] = oy;
+            off_n[r] = on;
+            sx[slot] = ox + vx;
+            sy[slot] = oy + vy;
+            sn[slot] = on + vn;
+        }
+        __syncthreads();
+        const int u = used;   // read between two barriers: the same value in every thread
+        __syncthreads();
+        if (u > kT2Cap) {
+            overflow = true;
+            break;
+        }
+    }
+    if (overflow) {
+        if (tid == 0) flags[1] = 1;
+        return;
+    }
+    for (int s = tid; s < kT2; s += kT1) {
+        const int k = key[s];
+        if (k != kEmpty && k < L) {
+            ms_x[(size_t)sc * L + k] = sx[s];
+            ms_y[(size_t)sc * L + k] = sy[s];
+            ms_n[(size_t)sc * L + k] = sn[s];
+        }
+    }
+}
+
+// Level 3: exclusive prefix down each landmark's column of the (zero-initialised) matrix.
+// stats != nullptr: the rank's totals for the exchange [sx(L) | sy(L) | n(L)]; else the raw map.
+__global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, const int* __restrict__ n_new_dev,
+                                                  double* __restrict__ ms_x, double* __restrict__ ms_y,
+                                                  double* __restrict__ ms_n, double* __restrict__ stats,
+                                                  double* __restrict__ y_raw, double* __restrict__ cnt_raw) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= L) return;
+    double ax = 0.0, ay = 0.0, an = 0.0;
+    if (i < lact0 + *n_new_dev) {  // columns of labels that do not exist are all zero
+        constexpr int kBatch = 8;   // loads of a batch are issued together, then the stores
+        for (int s0 = 0; s0 < nsuper; s0 += kBatch) {
+            double vx[kBatch], vy[kBatch], vn[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                const size_t q = (size_t)min(s0 + b, nsuper - 1) * L + i;
+                vx[b] = ms_x[q];
+                vy[b] = ms_y[q];
+                vn[b] = ms_n[q];
+            }
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                if (s0 + b < nsuper) {
+                    const size_t q = (size_t)(s0 + b) * L + i;
+                    ms_x[q] = ax;
+                    ms_y[q] = ay;
+                    ms_n[q] = an;
+                    ax += vx[b];
+                    ay += vy[b];
+                    an += vn[b];
+                }
+            }
+        }
+    }
+    if (stats) {
+        stats[i] = ax;
+        stats[L + i] = ay;
+        stats[2 * L + i] = an;
+    } else {
+        cnt_raw[i] = an;
+        y_raw[i] = an > 0.0 ? ax / an : 0.0;
+        y_raw[L + i] = an > 0.0 ? ay / an : 0.0;
+    }
+}
+
+// Sums before each record's chunk: lower ranks (rank_*; null on a single rank) + the
+// superchunks before + the chunks before inside the superchunk.  In place on off_*.
+__global__ __launch_bounds__(kBlock) void k_rec_push(int nrec, int G, int L, const int* __restrict__ rec_label,
+                                                     const double* __restrict__ ms_x, const double* __restrict__ ms_y,
+                                                     const double* __restrict__ ms_n, const double* __restrict__ rank_x,
+                                                     const double* __restrict__ rank_y, const double* __restrict__ rank_n,
+                                                     double* __restrict__ off_x, double* __restrict__ off_y,
+                                                     double* __restrict__ off_n) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= nrec) return;
+    const int lab = rec_label[r];
+    if (lab == kEmpty || lab >= L) return;
+    const size_t q = (size_t)((r / kT1) / G) * L + lab;
+    double bx = ms_x[q], by = ms_y[q], bn = ms_n[q];
+    if (rank_n) {
+        bx = rank_x[lab] + bx;
+        by = rank_y[lab] + by;
+        bn = rank_n[lab] + bn;
+    }
+    off_x[r] = bx + off_x[r];
+    off_y[r] = by + off_y[r];
+    off_n[r] = bn + off_n[r];
+}
+
+// ---------------------------------------------------------------------------------------
 // Phase D on the GPU: Mapa.filtrar (reference scripts/ICM_SLAM_tools.py:204-265) and the search
 // grid of the refined map, fused in ONE single-workgroup kernel (the map is a few thousand
 // landmarks: every step is a handful of items per thread, the cost is launch latency, so one
@@ -1296,6 +1671,67 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments(const double* __restric
         pose_m[(size_t)14 * nloc + tl] = pose_c[3 * (size_t)tl];
         pose_m[(size_t)15 * nloc + tl] = pose_c[3 * (size_t)tl + 1];
         pose_m[(size_t)16 * nloc + tl] = pose_c[3 * (size_t)tl + 2];
+    }
+}
+
+// The same moments straight from the staged entries and the hierarchical prefixes (k_chunk_l1 ..
+// k_rec_push): target = (sums before the chunk + sums inside the chunk through this pose) / n.
+// Also folds in what k_compact does for the sort-based pipeline (rotated mean body point,
+// scatter term), so the staged entries are read exactly once more.
+__global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restrict__ x, const double* __restrict__ x0,
+                                                           int t_begin, int nloc, const int* __restrict__ boff,
+                                                           const int* __restrict__ nent, const int* __restrict__ ent_off,
+                                                           const int* __restrict__ st_k, const double* __restrict__ st_sbx,
+                                                           const double* __restrict__ st_sby,
+                                                           const double* __restrict__ pose_s2,
+                                                           const double* __restrict__ pre_x, const double* __restrict__ pre_y,
+                                                           const double* __restrict__ pre_n, const int* __restrict__ e_rec,
+                                                           const double* __restrict__ off_x, const double* __restrict__ off_y,
+                                                           const double* __restrict__ off_n, double* __restrict__ pose_m,
+                                                           double2* __restrict__ tgt_out) {
+    const int sub = threadIdx.x & 15;
+    const int tl = (blockIdx.x * kBlock + threadIdx.x) >> 4;
+    const bool live = tl < nloc;
+    double px = 0.0, py = 0.0, th = 0.0;
+    int j0 = 0, e0 = 0, n = 0;
+    if (live) {
+        pose_of(x, x0, t_begin + tl, px, py, th);
+        j0 = boff[tl];
+        e0 = ent_off[tl];
+        n = nent[tl];
+    }
+    const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
+    double m[kMomentCount];
+#pragma unroll
+    for (int q = 0; q < kMomentCount; ++q) m[q] = 0.0;
+    double mxx = 0.0, mxy = 0.0, myy = 0.0;
+    for (int q = sub; q < n; q += 16) {
+        const double k = (double)st_k[j0 + q], sbx = st_sbx[j0 + q], sby = st_sby[j0 + q];
+        const int r = e_rec[e0 + q];
+        const double sx = off_x[r] + pre_x[e0 + q], sy = off_y[r] + pre_y[e0 + q], sn = off_n[r] + pre_n[e0 + q];
+        const double tx = sx / sn, ty = sy / sn;
+        if (tgt_out) tgt_out[e0 + q] = make_double2(tx, ty);   // association dump (icm_set_debug)
+        const double wx = (ct * sbx - st * sby) / k, wy = (st * sbx + ct * sby) / k;
+        const double rx = (px + wx) - tx, ry = (py + wy) - ty;
+        m[0] += k; m[1] += k * wx; m[2] += k * wy; m[3] += k * rx; m[4] += k * ry;
+        m[5] += k * wx * wx; m[6] += k * wy * wy; m[7] += k * wx * wy;
+        m[8] += k * wx * rx; m[9] += k * wy * rx; m[10] += k * wx * ry; m[11] += k * wy * ry;
+        m[12] += k * rx * rx; m[13] += k * ry * ry;
+        mxx += sbx * sbx / k;
+        mxy += sbx * sby / k;
+        myy += sby * sby / k;
+    }
+#pragma unroll
+    for (int q = 0; q < kMomentCount; ++q) m[q] = row_sum16(m[q]);
+    mxx = row_sum16(mxx);
+    mxy = row_sum16(mxy);
+    myy = row_sum16(myy);
+    if (live && sub == 0) {
+#pragma unroll
+        for (int q = 0; q < kMomentCount; ++q) pose_m[(size_t)q * nloc + tl] = m[q];
+        pose_m[(size_t)14 * nloc + tl] = pose_s2[3 * (size_t)tl] - mxx;
+        pose_m[(size_t)15 * nloc + tl] = pose_s2[3 * (size_t)tl + 1] - mxy;
+        pose_m[(size_t)16 * nloc + tl] = pose_s2[3 * (size_t)tl + 2] - myy;
     }
 }
 

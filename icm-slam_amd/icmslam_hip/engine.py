@@ -336,6 +336,15 @@ class SweepEngine:
         """-1 automatic, 0 one lane per pose, 1 one quad per pose (latency form)."""
         self._chk(self.lib.icm_set_solve_lanes(self.h, int(mode)))
 
+    def set_entry_path(self, mode):
+        """-1 / 1 / 'hier': hierarchical running sums (default); 0 / 'sort': the sort-based pipeline."""
+        mode = {"hier": 1, "sort": 0, "auto": -1}.get(mode, mode)
+        self._chk(self.lib.icm_set_entry_path(self.h, int(mode)))
+
+    def entry_path(self):
+        """Pipeline the last sweep ran: 'hier' or 'sort'."""
+        return "hier" if self.lib.icm_get_entry_path(self.h) == 1 else "sort"
+
     def set_gpu_filtrar(self, on):
         self._chk(self.lib.icm_set_gpu_filtrar(self.h, int(bool(on))))
 

@@ -189,6 +189,18 @@ int icm_set_energy_form(icm_handle *h, int form);
  * Bit-identical results. */
 int icm_set_solve_lanes(icm_handle *h, int mode);
 
+/* Pipeline that turns the per-pose entries into running-mean targets (the time-ordered
+ * per-landmark prefix of Mapa.actualizar, scripts/ICM_SLAM_tools.py:184-196):
+ *   1 / -1 (default) = hierarchical running sums (pose chunks -> superchunks -> per-landmark
+ *       column prefix; no sort); used for the moment-form solves.  A map so dense that a
+ *       64-pose chunk sees more than ~190 distinct landmarks makes the sweep fall back to
+ *   0 = the sort-based pipeline (radix sort of the entries by landmark + one wave per
+ *       landmark), which has no such limit and also serves energy forms 1/2 and icm_set_debug.
+ * The two differ only in the order the per-landmark sums are added up (~1e-15 relative).
+ * icm_get_entry_path: pipeline the last sweep actually ran (0 or 1). */
+int icm_set_entry_path(icm_handle *h, int mode);
+int icm_get_entry_path(const icm_handle *h);
+
 /* Where Mapa.filtrar runs inside a sweep: 1 (default) = fused GPU kernel `k_filtrar_grid`
  * (falls back to the host routine when landmarks have to be merged), 0 = always the host
  * routine icm_filtrar.  Same results. */

@@ -46,6 +46,7 @@ def test_virtual_ranks_match_unsharded(world):
         runners.append(run)
     run_virtual_ranks(engines, sweeps)
     torch.cuda.synchronize()
+    assert all(e.entry_path() == "hier" for e in engines), "the sharded sweep runs the hierarchical pipeline"
     for e in engines:
         x, m, c, K = e.get_state()
         assert K == K1
