@@ -108,6 +108,7 @@ struct icm_handle {
     bool hier_ok = true;     // cleared by an overflow until the next icm_set_state
     int path_used = 0;       // pipeline of the last sweep: 0 sort-based, 1 hierarchical
     double* stats_all = nullptr;
+    double *stats_send = nullptr, *halo_send = nullptr, *halo_all = nullptr;   // optional (icm_bind_exchange_send)
     int rank = 0, world = 1;
     int64_t E = 0, n_new_loc = 0, lact_raw = 0;
     int lact0 = 0;
@@ -446,6 +447,55 @@ int icm_bind_exchange(icm_handle* h, void* stats_all_dev, int rank, int world) {
     return ICM_OK;
 }
 
+int icm_bind_exchange_send(icm_handle* h, void* stats_send_dev, void* halo_send_dev, void* halo_all_dev) {
+    if (!h) return ICM_ERR_ARG;
+    if ((halo_send_dev == nullptr) != (halo_all_dev == nullptr)) FAIL(h, ICM_ERR_ARG, "icm_bind_exchange_send: halo_send and halo_all go together");
+    h->stats_send = reinterpret_cast<double*>(stats_send_dev);
+    h->halo_send = reinterpret_cast<double*>(halo_send_dev);
+    h->halo_all = reinterpret_cast<double*>(halo_all_dev);
+    return ICM_OK;
+}
+
+// first / last pose of the shard, clamped into the sequence (an empty shard sends pose values nobody reads)
+static int edge_first(const icm_handle* h) { return (int)std::min<int64_t>(h->t_begin, std::max<int64_t>(h->T - 1, 0)); }
+static int edge_last(const icm_handle* h) {
+    return (int)std::min<int64_t>(std::max<int64_t>(h->t_begin + h->nloc - 1, 0), std::max<int64_t>(h->T - 1, 0));
+}
+
+// this rank's slot of the landmark statistics: the send buffer if one is bound
+static double* stats_slot(icm_handle* h) {
+    return h->stats_send ? h->stats_send : h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h);
+}
+
+__global__ void k_halo_pack(const double* __restrict__ x, int first, int last, double* __restrict__ send) {
+    const int i = threadIdx.x;
+    if (i < 3) send[i] = x[3 * (size_t)first + i];
+    else if (i < 6) send[i] = x[3 * (size_t)last + (i - 3)];
+}
+
+__global__ void k_halo_unpack(double* __restrict__ x, const double* __restrict__ all, int rank, int below, int above) {
+    const int i = threadIdx.x;  // below / above: pose index to fill, -1 = none
+    if (i < 3) {
+        if (below >= 0) x[3 * (size_t)below + i] = all[6 * (size_t)(rank - 1) + 3 + i];
+    } else if (i < 6) {
+        if (above >= 0) x[3 * (size_t)above + (i - 3)] = all[6 * (size_t)(rank + 1) + (i - 3)];
+    }
+}
+
+int icm_halo_unpack(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->halo_all) FAIL(h, ICM_ERR_ARG, "icm_halo_unpack: no halo buffers bound (icm_bind_exchange_send)");
+    if (!h->uploaded || h->nloc == 0) return ICM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int a = (int)h->t_begin, b = (int)(h->t_begin + h->nloc);
+    const int below = (a > 0 && h->rank > 0) ? a - 1 : -1;
+    const int above = (b < (int)h->T && h->rank + 1 < h->world) ? b : -1;
+    if (below < 0 && above < 0) return ICM_OK;
+    k_halo_unpack<<<1, 8, 0, h->stream>>>(h->x, h->halo_all, h->rank, below, above);
+    HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
 int icm_bind_pose_buffer(icm_handle* h, void* x_dev) {
     if (!h) return ICM_ERR_ARG;
     if (!x_dev) FAIL(h, ICM_ERR_ARG, "icm_bind_pose_buffer: null buffer");
@@ -464,9 +514,27 @@ void* icm_pose_buffer(icm_handle* h) {
     return h->x;
 }
 
-__global__ void k_set_header(double* stats, int L, double n_new, double flags) {
-    stats[3 * (size_t)L] = n_new;
-    stats[3 * (size_t)L + 1] = flags;
+// header of a rank's statistics message: [0] new landmarks, [1] flags, [2..4] first pose of the
+// shard, [5..7] last pose -- the boundary poses ride along, so the halo exchange that would
+// precede the next odd half sweep needs no collective of its own
+__global__ void k_set_header(double* stats, int L, double n_new, double flags, const double* __restrict__ x, int first, int last) {
+    double* hd = stats + 3 * (size_t)L;
+    hd[0] = n_new;
+    hd[1] = flags;
+    for (int i = 0; i < 3; ++i) {
+        hd[2 + i] = x[3 * (size_t)first + i];
+        hd[5 + i] = x[3 * (size_t)last + i];
+    }
+}
+
+__global__ void k_halo_from_headers(double* __restrict__ x, const double* __restrict__ stats_all, int stride, int L, int rank,
+                                    int below, int above) {
+    const int i = threadIdx.x;
+    if (i < 3) {
+        if (below >= 0) x[3 * (size_t)below + i] = stats_all[(size_t)(rank - 1) * stride + 3 * (size_t)L + 5 + i];
+    } else if (i < 6) {
+        if (above >= 0) x[3 * (size_t)above + (i - 3)] = stats_all[(size_t)(rank + 1) * stride + 3 * (size_t)L + 2 + (i - 3)];
+    }
 }
 
 // Phase A + local statistics.
@@ -524,7 +592,7 @@ int icm_sweep_local(icm_handle* h) {
             TIMED(h, KID_CHUNK_L2, (k_chunk_l2<<<h->nsuper, kT1, 0, h->stream>>>(
                 h->nchunks, h->chunk_group, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
                 h->rec_off.p, h->rec_off.p + nrec, h->rec_off.p + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->flags.p)));
-            double* stats_mine = h->world > 1 ? h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h) : nullptr;
+            double* stats_mine = h->world > 1 ? stats_slot(h) : nullptr;
             TIMED(h, KID_LM_L3, (k_lm_l3<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, h->new_rank.p + nloc, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p)));
         }
         HIPCHK(h, hipMemcpyAsync(h->pin_i, h->ent_off.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -554,7 +622,7 @@ int icm_sweep_local(icm_handle* h) {
     }
     h->path_used = hier ? 1 : 0;
     if (hier) {
-        if (h->world > 1) k_set_header<<<1, 1, 0, h->stream>>>(h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h), L, (double)h->n_new_loc, 0.0);
+        if (h->world > 1) k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, (double)h->n_new_loc, 0.0, h->x, edge_first(h), edge_last(h));
         HIPCHK(h, hipGetLastError());
         return ICM_OK;
     }
@@ -566,9 +634,9 @@ int icm_sweep_local(icm_handle* h) {
         TIMED(h, KID_SORT, HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp.p, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, (size_t)E, 0, bits, h->stream)));
     TIMED(h, KID_LM_BOUNDS, (k_lm_bounds<<<nblocks_threads(nlab + 1), kBlock, 0, h->stream>>>(h->skey.p, E, nlab, h->lm_off.p)));
     if (h->world > 1) {
-        double* stats_mine = h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h);
+        double* stats_mine = stats_slot(h);
         TIMED(h, KID_LM_TOTALS, (k_lm_scan<true><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, nullptr, nullptr, nullptr, nullptr, stats_mine, nullptr, nullptr)));
-        k_set_header<<<1, 1, 0, h->stream>>>(stats_mine, L, (double)h->n_new_loc, 0.0);
+        k_set_header<<<1, 1, 0, h->stream>>>(stats_mine, L, (double)h->n_new_loc, 0.0, h->x, edge_first(h), edge_last(h));
     }
     HIPCHK(h, hipGetLastError());
     return ICM_OK;
@@ -582,6 +650,14 @@ int icm_sweep_targets(icm_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     const int nlab = h->lact0 + (int)h->n_new_loc;
+    if (h->world > 1 && h->halo_all) {
+        // the neighbours' boundary poses came with their statistics
+        const int a = (int)h->t_begin, b = (int)(h->t_begin + h->nloc);
+        const int below = (a > 0 && h->rank > 0) ? a - 1 : -1;
+        const int above = (b < (int)h->T && h->rank + 1 < h->world) ? b : -1;
+        if (below >= 0 || above >= 0)
+            k_halo_from_headers<<<1, 8, 0, h->stream>>>(h->x, h->stats_all, (int)icm_stats_stride(h), L, h->rank, below, above);
+    }
     if (h->path_used == 1) {
         const int nrec = h->nchunks * kT1;
         const size_t msn = (size_t)h->nsuper * (size_t)L;
@@ -689,6 +765,8 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     } else {
         FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: unknown schedule");
     }
+    if (h->halo_send && h->nloc > 0)
+        k_halo_pack<<<1, 8, 0, h->stream>>>(h->x, edge_first(h), edge_last(h), h->halo_send);
     HIPCHK(h, hipGetLastError());
     return ICM_OK;
 }

@@ -45,6 +45,8 @@ SIGNATURES = {
     "icm_get_state": (C.c_int, [_H, _dp, _dp, _dp, _lp]),
     "icm_stats_stride": (C.c_int64, [_H]),
     "icm_bind_exchange": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    "icm_bind_exchange_send": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "icm_halo_unpack": (C.c_int, [_H]),
     "icm_bind_pose_buffer": (C.c_int, [_H, C.c_void_p]),
     "icm_pose_buffer": (C.c_void_p, [_H]),
     "icm_sweep_local": (C.c_int, [_H]),

@@ -269,6 +269,13 @@ class SweepEngine:
     def bind_exchange(self, stats_ptr, rank, world):
         self._chk(self.lib.icm_bind_exchange(self.h, C.c_void_p(stats_ptr), int(rank), int(world)))
 
+    def bind_exchange_send(self, stats_send_ptr, halo_send_ptr, halo_all_ptr):
+        self._chk(self.lib.icm_bind_exchange_send(self.h, C.c_void_p(stats_send_ptr), C.c_void_p(halo_send_ptr),
+                                                  C.c_void_p(halo_all_ptr)))
+
+    def halo_unpack(self):
+        self._chk(self.lib.icm_halo_unpack(self.h))
+
     def set_stream(self, stream_ptr):
         self._chk(self.lib.icm_set_stream(self.h, C.c_void_p(stream_ptr)))
 

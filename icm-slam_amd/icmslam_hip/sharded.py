@@ -13,7 +13,8 @@ Per sweep:
   4. halo exchange: a solve reads only the poses t-1 and t+1, so a shard needs one pose from
      each neighbour -- every rank contributes its first and last pose (48 B) to one tiny
      all-gather and copies the two it needs next to its block
-  5. the even poses, halo exchange again (the next sweep's odd half reads them)
+  5. the even poses; their boundary values travel in the header of the NEXT sweep's statistics
+     message (step 2), so a sweep costs two collectives
   6. Mapa.filtrar, replicated (deterministic) on every rank
 
 The pose blocks themselves are gathered only when the caller asks for the state
@@ -47,6 +48,8 @@ class ShardedSweep:
         else:
             stats, poses = buffers
         self.stats, self.poses = stats, poses
+        self.comm = comm if comm is not None else TorchComm()
+        self.native = False
         if hasattr(engine, "bind_tensors"):      # test doubles work on the tensors directly
             engine.bind_tensors(stats, poses, rank, world)
         else:
@@ -54,7 +57,15 @@ class ShardedSweep:
                 engine.set_stream(torch.cuda.current_stream().cuda_stream)
             engine.bind_exchange(stats.data_ptr(), rank, world)
             engine.bind_pose_buffer(poses.data_ptr())
-        self.comm = comm if comm is not None else TorchComm()
+            if not isinstance(self.comm, NoComm):
+                # real collectives: the library writes the send-side buffers (its statistics; its
+                # first and last pose after every half sweep) and unpacks the neighbours' poses,
+                # so that each exchange is one collective call and one C call
+                self.stats_send = torch.zeros(self.stride, dtype=torch.float64, device=dev)
+                self.halo_send = torch.zeros(6, dtype=torch.float64, device=dev)
+                self.halo_recv = torch.zeros(world * 6, dtype=torch.float64, device=dev)
+                engine.bind_exchange_send(self.stats_send.data_ptr(), self.halo_send.data_ptr(), self.halo_recv.data_ptr())
+                self.native = True
         # halo bookkeeping: rows (first pose, last pose) of every rank; which of them this rank
         # needs (the last pose of the rank below, the first pose of the rank above; only trailing
         # ranks can be empty, and an empty rank needs nothing)
@@ -83,12 +94,13 @@ class ShardedSweep:
             raise NotImplementedError("only the red-black schedule shards (the reference order is one chain)")
         e, r = self.eng, self.rank
         e.sweep_local()
-        self.comm.all_gather(self.stats, r, self.stride)
+        self.comm.gather_stats(self)
         e.sweep_targets()
         e.sweep_solve("redblack", 1)
         self.comm.halo(self)
         e.sweep_solve("redblack", 0)
-        self.comm.halo(self)
+        if not self.native:      # (native: the even poses' boundary values ride in the next statistics message)
+            self.comm.halo(self)
         e.sweep_finish()
 
     def get_state(self):
@@ -108,7 +120,17 @@ class TorchComm:
         mine = buf[rank * count:(rank + 1) * count].clone()
         self.dist.all_gather_into_tensor(buf, mine, group=self.group)
 
+    def gather_stats(self, sw):
+        if sw.native:
+            self.dist.all_gather_into_tensor(sw.stats, sw.stats_send, group=self.group)
+        else:
+            self.all_gather(sw.stats, sw.rank, sw.stride)
+
     def halo(self, sw):
+        if sw.native:   # packed by icm_sweep_solve, unpacked by icm_halo_unpack
+            self.dist.all_gather_into_tensor(sw.halo_recv, sw.halo_send, group=self.group)
+            sw.eng.halo_unpack()
+            return
         P = sw.poses.view(-1, 3)
         edges = P.index_select(0, sw.edge_idx)                       # (2,3): my first and last pose
         self.dist.all_gather_into_tensor(sw.halo_all, edges, group=self.group)
@@ -121,6 +143,9 @@ class NoComm:
     slot is already visible to the others."""
 
     def all_gather(self, buf, rank, count):
+        pass
+
+    def gather_stats(self, sw):
         pass
 
     def halo(self, sw):

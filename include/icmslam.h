@@ -113,6 +113,22 @@ int icm_get_state(icm_handle *h, double *x, double *map_out, double *counts_out,
  * (see icm_bind_pose_buffer). */
 int64_t icm_stats_stride(const icm_handle *h);
 int icm_bind_exchange(icm_handle *h, void *stats_all_dev, int rank, int world);
+/* Optional send-side buffers, so that each exchange is ONE collective call and nothing else
+ * on the caller's side (all-gather input and output must not alias):
+ *   stats_send [icm_stats_stride()] doubles: icm_sweep_local() writes this rank's statistics
+ *              here (instead of into its slice of stats_all); the caller all-gathers
+ *              stats_send -> stats_all.
+ *   halo_send [6] doubles: after every icm_sweep_solve() the first and the last pose of the
+ *              shard, (x, y, theta) each; the caller all-gathers halo_send -> halo_all
+ *              [world * 6] and calls icm_halo_unpack(), which copies the last pose of rank-1
+ *              and the first pose of rank+1 next to the shard in the pose buffer (a solve
+ *              reads only poses t-1 and t+1, scripts/ICM_ROS.py:211-214).  With halo buffers
+ *              bound, the statistics message also carries the shard's boundary poses in its
+ *              header and icm_sweep_targets() unpacks them, so a sweep needs the halo
+ *              exchange only between its two half sweeps.
+ * Any pointer may be null (that exchange then works in place as described above). */
+int icm_bind_exchange_send(icm_handle *h, void *stats_send_dev, void *halo_send_dev, void *halo_all_dev);
+int icm_halo_unpack(icm_handle *h);
 /* Use caller-owned device memory for the poses: (T,3) doubles, pose-major (a contiguous
  * block of poses is a contiguous block of memory, so shards all-gather in place).  Call
  * before icm_set_state. */

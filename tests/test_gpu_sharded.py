@@ -83,3 +83,78 @@ def test_rccl_all_gather_path_one_rank():
     finally:
         dist.destroy_process_group()
     assert K == K1 and np.array_equal(x, x1) and np.array_equal(m, m1)
+
+
+def _native_worker(rank, world, port, out_path):
+    """One rank of a multi-process sharded sweep; every rank uses cuda:0 (one-GPU box), the
+    collectives go through gloo -- the path under test is the library's send-side buffers
+    (icm_bind_exchange_send), halo pack in icm_sweep_solve and icm_halo_unpack."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "icm-slam_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import ShardedSweep, TorchComm, partition
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+
+    class HostHopComm(TorchComm):
+        """TorchComm whose all-gathers hop through host memory (gloo has no device collectives)."""
+
+        def _ag(self, out, inp):
+            o, i = out.cpu(), inp.cpu()
+            self.dist.all_gather_into_tensor(o, i, group=self.group)
+            out.copy_(o)
+
+        def gather_stats(self, sw):
+            assert sw.native
+            self._ag(sw.stats, sw.stats_send)
+
+        def halo(self, sw):
+            assert sw.native
+            self._ag(sw.halo_recv, sw.halo_send)
+            sw.eng.halo_unpack()
+
+        def all_gather(self, buf, r, count):
+            mine = buf[r * count:(r + 1) * count].clone()
+            self._ag(buf, mine)
+
+    wl, cfg = _workload()
+    _, parts = partition(wl.T, world)
+    a, b = parts[rank]
+    e = SweepEngine(cfg)
+    e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
+    run = ShardedSweep(e, rank, world, wl.T, comm=HostHopComm())
+    assert run.native
+    run.set_state(wl.map_init, wl.x_init, wl.x0)
+    for _ in range(3):
+        run.sweep("redblack")
+    torch.cuda.synchronize()
+    x, m, c, K = run.get_state()
+    np.savez(out_path % rank, x=x, m=m[:, :K], c=c, K=K, path=e.entry_path())
+    e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_processes_library_side_halo(tmp_path):
+    """Three OS processes (ranks) on the one GPU, real exchanges between them: the library's
+    send buffers + halo pack/unpack give the unsharded result; the interior rank has a
+    neighbour on both sides."""
+    import torch.multiprocessing as mp
+    world = 3
+    wl, cfg = _workload()
+    x1, m1, c1, K1 = _single(wl, cfg, 3)
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_native_worker, args=(world, 29561, out), nprocs=world, join=True)
+    for r in range(world):
+        g = np.load(out % r)
+        assert str(g["path"]) == "hier"
+        assert int(g["K"]) == K1 and np.array_equal(g["c"], c1)
+        assert np.abs(g["m"] - m1[:, :K1]).max() <= 1e-9
+        d = np.abs(g["x"] - x1).max(axis=0)
+        print("rank %d: max|dx| %.3e, poses above 1e-9: %d" % (r, d.max(), int((d > 1e-9).sum())))
+        assert d.max() <= 5e-3 and (d > 1e-9).sum() <= 3
