@@ -318,9 +318,10 @@ struct GridView {
 };
 
 __device__ __forceinline__ int grid_cell(double v, double g0, double inv, int n) {
-    double f = floor((v - g0) * inv);
-    f = fmin(fmax(f, 0.0), (double)(n - 1));  // NaN -> 0
-    return (int)f;
+    // floor + clamp to [0, n-1] in integer arithmetic: the conversion truncates toward zero (so
+    // (-1, 0) -> 0 like the clamp would), saturates for huge values and maps NaN to 0
+    const int c = (int)((v - g0) * inv);
+    return min(max(c, 0), n - 1);
 }
 
 __device__ __forceinline__ void pose_of(const double* __restrict__ x, const double* __restrict__ x0, int tg,
@@ -330,6 +331,16 @@ __device__ __forceinline__ void pose_of(const double* __restrict__ x, const doub
     } else {
         px = x[3 * (size_t)tg]; py = x[3 * (size_t)tg + 1]; th = x[3 * (size_t)tg + 2];
     }
+}
+
+// cos / sin of (theta - pi/2): the rotation tras_rot_z applies (scripts/ICM_SLAM_tools.py:476-479).
+// One argument reduction for both (the same one every kernel uses, so all of them rotate a
+// pose's beams with identical coefficients).
+__device__ __forceinline__ void pose_rot(double th, double& ct, double& st) {
+    double s_, c_;
+    sincos(th - kHalfPi, &s_, &c_);
+    ct = c_;
+    st = s_;
 }
 
 // Gated nearest landmark of the world point (wx, wy).  The three cell rows around the point
@@ -475,7 +486,8 @@ __global__ __launch_bounds__(kBlock) void k_associate_brute(const double* __rest
         j1 = boff[tl + 1];
         pose_of(x, x0, t_begin + tl, px, py, th);
     }
-    const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
+    double ct, st;
+    pose_rot(th, ct, st);
     const int iters = (j1 - j0 + kWave - 1) / kWave;
     if (threadIdx.x == 0) s_maxit = 0;
     __syncthreads();
@@ -593,7 +605,8 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     }
     double px, py, th;
     pose_of(x, x0, t_begin + tl, px, py, th);
-    const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
+    double ct, st;
+    pose_rot(th, ct, st);
     const GridParams gp = *g.par;
     int nent = 0;
     bool overflow = false;
@@ -640,7 +653,7 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         seg_step<0x111, 0xF>(dist >= 1, ax, ay);
         seg_step<0x112, 0xF>(dist >= 2, ax, ay);
         seg_step<0x114, 0xF>(dist >= 4, ax, ay);
-        seg_step<0x118, 0xF>(dist >= 8, ax, ay);
+        if (__ballot(dist >= 8) != 0ull) seg_step<0x118, 0xF>(dist >= 8, ax, ay);   // (wave-uniform skip)
         seg_step<0x142, 0xA>(dist > (lane & 15), ax, ay);   // run began in an earlier row
         seg_step<0x143, 0xC>(dist > (lane & 31), ax, ay);   // run began in rows 0-1
         const int nexthead = __shfl_down(head ? 1 : 0, 1, kWave);
@@ -761,7 +774,8 @@ __global__ __launch_bounds__(kBlock) void k_compact(const double* __restrict__ x
         nrank = new_rank[tl];
         pose_of(x, x0, t_begin + tl, px, py, th);
     }
-    const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
+    double ct, st;
+    pose_rot(th, ct, st);
     double mxx = 0.0, mxy = 0.0, myy = 0.0;
     for (int q = sub; q < n; q += 16) {
         int lab = st_label[j0 + q];
@@ -1052,7 +1066,8 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
     }
     EntryGroup cur, nxt;
     load_group(cur, 0, lane, n, j0, st_label, st_k, st_sbx, st_sby);
-    const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
+    double ct, st;
+    pose_rot(th, ct, st);
     __builtin_amdgcn_wave_barrier();
     bool overflow = false;
     for (int p0 = 0; p0 < kCH && !overflow; p0 += kGroup) {
@@ -1700,7 +1715,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
         e0 = ent_off[tl];
         n = nent[tl];
     }
-    const double ct = cos(th - kHalfPi), st = sin(th - kHalfPi);
+    double ct, st;
+    pose_rot(th, ct, st);
     double m[kMomentCount];
 #pragma unroll
     for (int q = 0; q < kMomentCount; ++q) m[q] = 0.0;
@@ -1928,7 +1944,8 @@ __global__ __launch_bounds__(kWave) void k_init_pass(InitArgs a) {
         if (n == 0) {  // no observation: keep the prediction (scripts/ICM_ROS.py:110-113)
             xt[0] = xc0; xt[1] = xc1; xt[2] = xc2;
         } else {
-            const double ct = cos(xc2 - kHalfPi), st = sin(xc2 - kHalfPi);
+            double ct, st;
+            pose_rot(xc2, ct, st);
             bool isnew = false;
             for (int j = lane; j < n; j += kWave) {
                 const double bxx = a.bx[j0 + j], byy = a.by[j0 + j];

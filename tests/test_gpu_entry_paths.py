@@ -146,3 +146,50 @@ def test_many_landmarks_per_chunk_still_hierarchical_or_falls_back_consistently(
     assert Ks == Kh and np.array_equal(cs, ch) and np.abs(ms - mh).max() <= 1e-11
     dd = np.abs(xs - xh).max(axis=0)
     assert dd.max() <= 5e-3 and (dd > 1e-9).sum() <= 3
+
+
+@pytest.mark.parametrize("mode", ["sort", "hier"])
+def test_new_landmarks_beyond_capacity_raise_index_error(mode):
+    """Mapa.actualizar indexes cant_obs_i[L] when a sweep creates more landmarks than the map has
+    room for (IndexError, scripts/ICM_SLAM_tools.py:191); both pipelines must refuse the same way
+    and leave the handle usable."""
+    from icmslam_hip import SweepEngine
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    la = int(init["landmarks_actuales"])
+    eng = SweepEngine(Cfg(L=la + 5))          # sweep 1 of the dataset creates 67 landmarks
+    eng.upload(zz, odo, u)
+    eng.set_entry_path(mode)
+    x = init["x_init"].copy()
+    with pytest.raises(IndexError):
+        eng.sweep(init["map_init"].copy(), x, odo[:, 0], la, "sequential")
+    eng.close()
+    # the same data with room to spare goes through
+    eng = SweepEngine(Cfg(L=la + 100))
+    eng.upload(zz, odo, u)
+    eng.set_entry_path(mode)
+    x = init["x_init"].copy()
+    mo, co, K = eng.sweep(init["map_init"].copy(), x, odo[:, 0], la, "sequential")
+    assert K == 11 and eng.entry_path() == mode
+    eng.close()
+
+
+def test_sequence_shorter_than_one_chunk():
+    """Fewer poses than one 64-pose chunk (and not a multiple of the group size)."""
+    from icmslam_hip import SweepEngine
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    T = 43
+    out = {}
+    for mode in ("sort", "hier"):
+        eng = SweepEngine(Cfg(cota=5.0))
+        eng.upload(zz[:, :T], odo[:, :T], u[:, :T])
+        eng.set_entry_path(mode)
+        x = np.ascontiguousarray(init["x_init"][:, :T]).copy()
+        mo, co, K = eng.sweep(init["map_init"].copy(), x, odo[:, 0], int(init["landmarks_actuales"]), "redblack")
+        assert eng.entry_path() == mode
+        out[mode] = (x, mo[:, :K], co)
+        eng.close()
+    assert np.array_equal(out["sort"][2], out["hier"][2])
+    assert np.abs(out["sort"][1] - out["hier"][1]).max() <= 1e-12
+    assert np.abs(out["sort"][0] - out["hier"][0]).max() <= 1e-9
