@@ -104,6 +104,10 @@ struct icm_handle {
     DevBuf<int> rec_label;
     DevBuf<double> rec_s, rec_off, ms;   // [3][nrec], [3][nrec], [3][nsuper][L]
     int nchunks = 0, chunk_group = 1, nsuper = 0;
+    DevBuf<int> solve_flags;  // per-wave completion flags of the fused red-black solve (+1: error word)
+    int solve_epoch = 0;
+    bool fused_used = false;
+    int fuse_colours = 1;    // 1: both colours of an unsharded red-black sweep in one launch (k_solve_m_fused)
     int entry_path = -1;     // -1 automatic, 0 sort-based pipeline, 1 hierarchical (falls back when a table overflows)
     bool hier_ok = true;     // cleared by an overflow until the next icm_set_state
     int path_used = 0;       // pipeline of the last sweep: 0 sort-based, 1 hierarchical
@@ -242,7 +246,7 @@ int icm_destroy(icm_handle* h) {
     h->e_key.release();
     h->skey.release();
     h->sort_tmp.release();
-    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release();
+    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release();
     if (h->pin_i) (void)hipHostFree(h->pin_i);
     if (h->pin_d) (void)hipHostFree(h->pin_d);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -746,6 +750,18 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
         else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_sequential<false><<<1, kWave, 0, h->stream>>>(a)));
         else TIMED(h, KID_SOLVE, (k_solve_m_sequential<<<1, kWave, 0, h->stream>>>(a)));
+    } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->world == 1 && h->t_begin == 0 && h->form == 0 && h->fuse_colours &&
+               h->solve_quad != 1 && (int64_t)(h->nloc / 2 + 1) * 4 > (int64_t)1024 * kWave) {
+        // both colours, unsharded, throughput form: one launch, even waves chase the odd ones
+        const int nwv = (int)((h->nloc / 2 + 1 + kWave - 1) / kWave);
+        if (h->solve_flags.cap < (size_t)nwv + 1) {
+            HIPCHK(h, h->solve_flags.reserve((size_t)nwv + 1));
+            HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, ((size_t)nwv + 1) * sizeof(int), h->stream));
+            h->solve_epoch = 0;
+        }
+        ++h->solve_epoch;
+        h->fused_used = true;
+        TIMED(h, KID_SOLVE, (k_solve_m_fused<<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->solve_flags.p + nwv)));
     } else if (schedule == ICM_SCHEDULE_REDBLACK) {
         const int nw = (int)(h->nloc / 2 + 1);
         for (int col = 1; col >= 0; --col) {
@@ -783,6 +799,13 @@ int icm_sweep_finish(icm_handle* h) {
     if (!h->map_copy_pending) FAIL(h, ICM_ERR_ARG, "icm_sweep_finish: call icm_sweep_targets first");
     HIPCHK(h, hipEventSynchronize(h->ev_copied));  // the solves may still be running
     h->map_copy_pending = false;
+    if (h->fused_used) {  // did an even wave give up waiting for its odd neighbours?
+        h->fused_used = false;
+        const int nwv = (int)((h->nloc / 2 + 1 + kWave - 1) / kWave);
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 4, h->solve_flags.p + nwv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->pin_i[4]) FAIL(h, ICM_ERR_HIP, "fused red-black solve: a wave timed out waiting for its neighbours (icm_set_colour_fusion(h, 0) selects two launches)");
+    }
     // total number of landmarks created this sweep, over all ranks
     int64_t n_new = h->n_new_loc;
     if (h->world > 1) {
@@ -1097,6 +1120,12 @@ int icm_set_solve_lanes(icm_handle* h, int mode) {
     if (!h) return ICM_ERR_ARG;
     if (mode < -1 || mode > 1) FAIL(h, ICM_ERR_ARG, "icm_set_solve_lanes: mode must be -1, 0 or 1");
     h->solve_quad = mode;
+    return ICM_OK;
+}
+
+int icm_set_colour_fusion(icm_handle* h, int on) {
+    if (!h) return ICM_ERR_ARG;
+    h->fuse_colours = on != 0;
     return ICM_OK;
 }
 

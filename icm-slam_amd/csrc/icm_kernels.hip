@@ -1827,6 +1827,57 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
     a.x[3 * (size_t)tg + 2] = res[2];
 }
 
+// Both half sweeps of an unsharded red-black sweep in ONE launch.  An even pose reads only its
+// two odd neighbours, so an even wave need not wait for the slowest odd pose of the whole
+// sequence (which is what a kernel boundary between the colours does) but only for the two odd
+// waves that hold its poses' neighbours.  Waves [0, nw) solve the odd poses and publish a
+// per-wave flag; waves [nw, 2 nw) poll the two flags they depend on, then solve the even poses.
+// The odd waves have the lower workgroup ids, are dispatched first and never wait, so the grid
+// always drains; a poll that sees nothing for seconds gives up and raises err[0].
+// Hand-off per MI355X_MICROARCH.md: producer = plain stores, vmcnt(0), agent release fence,
+// vmcnt(0), relaxed agent flag store; consumer = relaxed polls, ONE agent acquire fence,
+// vmcnt(0), then plain loads.  The odd waves that READ an even wave's poses (as the old values of
+// their neighbours) are exactly the two it waits for, so nothing is overwritten while in use.
+__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, int* __restrict__ flags, int epoch,
+                                                          int* __restrict__ err) {
+    const int lane = lane_id();
+    const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (gw >= 2 * nw) return;
+    const bool even = gw >= nw;
+    const int wv = even ? gw - nw : gw;
+    const int tg = (even ? 2 : 1) + 2 * (wv * kWave + lane);   // (unsharded: t_begin = 0)
+    if (even) {
+        if (lane == 0) {
+            for (int d = 0; d < 2 && wv + d < nw; ++d) {   // odd poses 2j+1, j in [64 wv, 64 wv + 64]
+                int spins = 0;
+                while (__hip_atomic_load(&flags[wv + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 24)) {
+                        atomicExch(err, 1);
+                        break;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (tg < a.nloc) {
+        double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
+        double res[3];
+        solve_pose_moments<false>(a, tg, prev, res);
+        a.x[3 * (size_t)tg] = res[0];
+        a.x[3 * (size_t)tg + 1] = res[1];
+        a.x[3 * (size_t)tg + 2] = res[2];
+    }
+    if (!even) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&flags[wv], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // The same half sweep in latency form: one DPP quad (4 lanes) per pose, 16 poses per wave
 // (nelder_mead3_quad).  Chosen by the host when a colour has too few poses to fill the chip.
 __global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, int colour) {

@@ -343,6 +343,10 @@ class SweepEngine:
         """-1 automatic, 0 one lane per pose, 1 one quad per pose (latency form)."""
         self._chk(self.lib.icm_set_solve_lanes(self.h, int(mode)))
 
+    def set_colour_fusion(self, on):
+        """True (default): both colours of an unsharded red-black sweep in one launch."""
+        self._chk(self.lib.icm_set_colour_fusion(self.h, int(bool(on))))
+
     def set_entry_path(self, mode):
         """-1 / 1 / 'hier': hierarchical running sums (default); 0 / 'sort': the sort-based pipeline."""
         mode = {"hier": 1, "sort": 0, "auto": -1}.get(mode, mode)

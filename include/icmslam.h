@@ -205,6 +205,11 @@ int icm_set_energy_form(icm_handle *h, int form);
  * Bit-identical results. */
 int icm_set_solve_lanes(icm_handle *h, int mode);
 
+/* Unsharded red-black sweeps in throughput form: 1 (default) = both colours in ONE launch, every
+ * even wave starting as soon as the two odd waves holding its poses' neighbours are done
+ * (k_solve_m_fused); 0 = one launch per colour.  Bit-identical results. */
+int icm_set_colour_fusion(icm_handle *h, int on);
+
 /* Pipeline that turns the per-pose entries into running-mean targets (the time-ordered
  * per-landmark prefix of Mapa.actualizar, scripts/ICM_SLAM_tools.py:184-196):
  *   1 / -1 (default) = hierarchical running sums (pose chunks -> superchunks -> per-landmark

@@ -362,3 +362,30 @@ def test_quad_latency_solver_is_bit_identical():
     e2.close()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+def test_fused_two_colour_launch_is_bit_identical():
+    """Unsharded red-black sweeps of a long sequence run both colours in one launch (even waves
+    wait for the two odd waves that hold their poses' neighbours): same poses and map, bit for
+    bit, as one launch per colour, over several sweeps."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    wl = make_workload(40_000, 4_000, 360)     # > 32768 poses: the throughput form of the solves
+    cfg = ConfigICM(D=wl.config)
+    eng = SweepEngine(cfg)
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    out = {}
+    for fuse in (False, True):
+        eng.set_colour_fusion(fuse)
+        eng.set_state(wl.map_init, wl.x_init, wl.x0)
+        eng.enable_timing(True)
+        for _ in range(4):
+            eng.sweep_device("redblack")
+        launches = eng.kernel_times()["k_solve"][1]
+        eng.enable_timing(False)
+        assert launches == (4 if fuse else 8)
+        out[fuse] = eng.get_state()
+    eng.close()
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
+    assert out[False][3] == out[True][3] and np.array_equal(out[False][2], out[True][2])
