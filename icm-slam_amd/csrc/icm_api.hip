@@ -107,6 +107,7 @@ struct icm_handle {
     DevBuf<int> solve_flags;  // per-wave completion flags of the fused red-black solve (+1: error word)
     int solve_epoch = 0;
     bool fused_used = false;
+    bool ms_clean = false;   // the [superchunk x L] matrix is zero (cleared on the side stream under the solves)
     int fuse_colours = 1;    // 1: both colours of an unsharded red-black sweep in one launch (k_solve_m_fused)
     int entry_path = -1;     // -1 automatic, 0 sort-based pipeline, 1 hierarchical (falls back when a table overflows)
     bool hier_ok = true;     // cleared by an overflow until the next icm_set_state
@@ -349,6 +350,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         const size_t nrec = (size_t)h->nchunks * kT1;
         HIPCHK(h, h->rec_label.reserve(nrec)); HIPCHK(h, h->rec_s.reserve(3 * nrec)); HIPCHK(h, h->rec_off.reserve(3 * nrec));
         HIPCHK(h, h->ms.reserve(3 * (size_t)h->nsuper * L));
+        h->ms_clean = false;
     }
     h->max_cells = (int)(8 * L + 4096);   // bound of both grid builders (build_grid, block_build_grid)
     HIPCHK(h, h->g_nb.reserve((size_t)h->max_cells));
@@ -592,16 +594,21 @@ int icm_sweep_local(icm_handle* h) {
                 h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->boff.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0,
                 h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, pre + 2 * nzs, h->e_val.p,
                 h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave)));
-            HIPCHK(h, hipMemsetAsync(ms, 0, 3 * msn * sizeof(double), h->stream));
+            if (!h->ms_clean) HIPCHK(h, hipMemsetAsync(ms, 0, 3 * msn * sizeof(double), h->stream));
+            h->ms_clean = false;
             TIMED(h, KID_CHUNK_L2, (k_chunk_l2<<<h->nsuper, kT1, 0, h->stream>>>(
                 h->nchunks, h->chunk_group, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
                 h->rec_off.p, h->rec_off.p + nrec, h->rec_off.p + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->flags.p)));
             double* stats_mine = h->world > 1 ? stats_slot(h) : nullptr;
-            TIMED(h, KID_LM_L3, (k_lm_l3<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, h->new_rank.p + nloc, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p)));
+            TIMED(h, KID_LM_L3, (k_lm_l3<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, h->new_rank.p + nloc, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p, h->ent_off.p + nloc, h->flags.p)));
         }
-        HIPCHK(h, hipMemcpyAsync(h->pin_i, h->ent_off.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->pin_i + 1, h->new_rank.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (hier) {  // k_lm_l3 gathered the four words
+            HIPCHK(h, hipMemcpyAsync(h->pin_i, h->flags.p + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        } else {
+            HIPCHK(h, hipMemcpyAsync(h->pin_i, h->ent_off.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->pin_i + 1, h->new_rank.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->pin_i[2] && h->hash_slots == 128) {  // a scan with > 96 distinct landmarks: use the larger table from now on
             h->hash_slots = 256;
@@ -720,6 +727,10 @@ int icm_sweep_targets(icm_handle* h) {
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
     }
+    if (h->path_used == 1) {  // next sweep's matrix: cleared here, under the solves (icm_sweep_finish waits for this stream)
+        HIPCHK(h, hipMemsetAsync(h->ms.p, 0, 3 * (size_t)h->nsuper * (size_t)L * sizeof(double), h->copy_stream));
+        h->ms_clean = true;
+    }
     HIPCHK(h, hipEventRecord(h->ev_copied, h->copy_stream));
     h->map_copy_pending = true;
     return ICM_OK;
@@ -761,7 +772,8 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         }
         ++h->solve_epoch;
         h->fused_used = true;
-        TIMED(h, KID_SOLVE, (k_solve_m_fused<<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->solve_flags.p + nwv)));
+        h->pin_i[4] = 0;   // (pinned host memory, mapped into the device: a wave that gives up waiting writes 1 here)
+        TIMED(h, KID_SOLVE, (k_solve_m_fused<<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->pin_i + 4)));
     } else if (schedule == ICM_SCHEDULE_REDBLACK) {
         const int nw = (int)(h->nloc / 2 + 1);
         for (int col = 1; col >= 0; --col) {
@@ -799,13 +811,6 @@ int icm_sweep_finish(icm_handle* h) {
     if (!h->map_copy_pending) FAIL(h, ICM_ERR_ARG, "icm_sweep_finish: call icm_sweep_targets first");
     HIPCHK(h, hipEventSynchronize(h->ev_copied));  // the solves may still be running
     h->map_copy_pending = false;
-    if (h->fused_used) {  // did an even wave give up waiting for its odd neighbours?
-        h->fused_used = false;
-        const int nwv = (int)((h->nloc / 2 + 1 + kWave - 1) / kWave);
-        HIPCHK(h, hipMemcpyAsync(h->pin_i + 4, h->solve_flags.p + nwv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (h->pin_i[4]) FAIL(h, ICM_ERR_HIP, "fused red-black solve: a wave timed out waiting for its neighbours (icm_set_colour_fusion(h, 0) selects two launches)");
-    }
     // total number of landmarks created this sweep, over all ranks
     int64_t n_new = h->n_new_loc;
     if (h->world > 1) {
@@ -823,7 +828,16 @@ int icm_sweep_finish(icm_handle* h) {
         h->K = h->lact = h->pin_i[8];
         h->h_map_valid = false;
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->fused_used) {  // did an even wave give up waiting for its odd neighbours?
+            h->fused_used = false;
+            if (h->pin_i[4]) FAIL(h, ICM_ERR_HIP, "fused red-black solve: a wave timed out waiting for its neighbours (icm_set_colour_fusion(h, 0) selects two launches)");
+        }
         return ICM_OK;
+    }
+    if (h->fused_used) {
+        h->fused_used = false;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->pin_i[4]) FAIL(h, ICM_ERR_HIP, "fused red-black solve: a wave timed out waiting for its neighbours (icm_set_colour_fusion(h, 0) selects two launches)");
     }
     std::vector<double> yo(2 * L), co(L);
     int64_t lact_new = 0;

@@ -1240,8 +1240,15 @@ __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, con
 __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, const int* __restrict__ n_new_dev,
                                                   double* __restrict__ ms_x, double* __restrict__ ms_y,
                                                   double* __restrict__ ms_n, double* __restrict__ stats,
-                                                  double* __restrict__ y_raw, double* __restrict__ cnt_raw) {
+                                                  double* __restrict__ y_raw, double* __restrict__ cnt_raw,
+                                                  const int* __restrict__ n_ent_dev, int* __restrict__ flags) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) {  // what the host reads back at its one synchronisation of the sweep, in one 16-byte copy
+        flags[4] = *n_ent_dev;
+        flags[5] = *n_new_dev;
+        flags[6] = flags[0];
+        flags[7] = flags[1];
+    }
     if (i >= L) return;
     double ax = 0.0, ay = 0.0, an = 0.0;
     if (i < lact0 + *n_new_dev) {  // columns of labels that do not exist are all zero
@@ -1853,7 +1860,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, i
                 while (__hip_atomic_load(&flags[wv + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > (1 << 24)) {
-                        atomicExch(err, 1);
+                        *reinterpret_cast<volatile int*>(err) = 1;   // (host-pinned word)
                         break;
                     }
                 }
