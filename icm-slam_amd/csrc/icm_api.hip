@@ -761,19 +761,22 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
         else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_sequential<false><<<1, kWave, 0, h->stream>>>(a)));
         else TIMED(h, KID_SOLVE, (k_solve_m_sequential<<<1, kWave, 0, h->stream>>>(a)));
-    } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->world == 1 && h->t_begin == 0 && h->form == 0 && h->fuse_colours &&
-               h->solve_quad != 1 && (int64_t)(h->nloc / 2 + 1) * 4 > (int64_t)1024 * kWave) {
-        // both colours, unsharded, throughput form: one launch, even waves chase the odd ones
-        const int nwv = (int)((h->nloc / 2 + 1 + kWave - 1) / kWave);
-        if (h->solve_flags.cap < (size_t)nwv + 1) {
-            HIPCHK(h, h->solve_flags.reserve((size_t)nwv + 1));
-            HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, ((size_t)nwv + 1) * sizeof(int), h->stream));
+    } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->world == 1 && h->t_begin == 0 && h->form == 0 && h->fuse_colours) {
+        // both colours of an unsharded sweep in one launch, even waves chase the odd ones
+        const int64_t npc = h->nloc / 2 + 1;   // poses per colour (upper bound)
+        const bool quad = h->solve_quad == 1 || (h->solve_quad < 0 && npc * 4 <= (int64_t)1024 * kWave);
+        const int ppw = quad ? kWave / 4 : kWave;
+        const int nwv = (int)((npc + ppw - 1) / ppw);
+        if (h->solve_flags.cap < (size_t)nwv) {
+            HIPCHK(h, h->solve_flags.reserve((size_t)nwv));
+            HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, (size_t)nwv * sizeof(int), h->stream));
             h->solve_epoch = 0;
         }
-        ++h->solve_epoch;
+        ++h->solve_epoch;   // (flags hold the epoch of the launch that set them: no reset between launches)
         h->fused_used = true;
         h->pin_i[4] = 0;   // (pinned host memory, mapped into the device: a wave that gives up waiting writes 1 here)
-        TIMED(h, KID_SOLVE, (k_solve_m_fused<<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->pin_i + 4)));
+        if (quad) TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->pin_i + 4)));
+        else TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->pin_i + 4)));
     } else if (schedule == ICM_SCHEDULE_REDBLACK) {
         const int nw = (int)(h->nloc / 2 + 1);
         for (int col = 1; col >= 0; --col) {

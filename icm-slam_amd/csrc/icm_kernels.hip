@@ -1845,17 +1845,21 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
 // vmcnt(0), relaxed agent flag store; consumer = relaxed polls, ONE agent acquire fence,
 // vmcnt(0), then plain loads.  The odd waves that READ an even wave's poses (as the old values of
 // their neighbours) are exactly the two it waits for, so nothing is overwritten while in use.
+// QUAD: the latency form (one DPP quad per pose, 16 poses per wave) with the same dependency rule.
+template <bool QUAD>
 __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, int* __restrict__ flags, int epoch,
                                                           int* __restrict__ err) {
+    constexpr int PPW = QUAD ? kWave / 4 : kWave;   // poses per wave
     const int lane = lane_id();
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (gw >= 2 * nw) return;
     const bool even = gw >= nw;
     const int wv = even ? gw - nw : gw;
-    const int tg = (even ? 2 : 1) + 2 * (wv * kWave + lane);   // (unsharded: t_begin = 0)
+    const int role = QUAD ? (lane & 3) : 0;
+    const int tg = (even ? 2 : 1) + 2 * (wv * PPW + (QUAD ? lane >> 2 : lane));   // (unsharded: t_begin = 0)
     if (even) {
         if (lane == 0) {
-            for (int d = 0; d < 2 && wv + d < nw; ++d) {   // odd poses 2j+1, j in [64 wv, 64 wv + 64]
+            for (int d = 0; d < 2 && wv + d < nw; ++d) {   // odd poses 2j+1, j in [PPW wv, PPW wv + PPW]
                 int spins = 0;
                 while (__hip_atomic_load(&flags[wv + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                     __builtin_amdgcn_s_sleep(8);
@@ -1869,13 +1873,15 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, i
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (tg < a.nloc) {
+    if (tg < a.nloc) {   // (whole quads together)
         double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
         double res[3];
-        solve_pose_moments<false>(a, tg, prev, res);
-        a.x[3 * (size_t)tg] = res[0];
-        a.x[3 * (size_t)tg + 1] = res[1];
-        a.x[3 * (size_t)tg + 2] = res[2];
+        solve_pose_moments<QUAD>(a, tg, prev, res, role);
+        if (role == 0) {
+            a.x[3 * (size_t)tg] = res[0];
+            a.x[3 * (size_t)tg + 1] = res[1];
+            a.x[3 * (size_t)tg + 2] = res[2];
+        }
     }
     if (!even) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -389,3 +389,20 @@ def test_fused_two_colour_launch_is_bit_identical():
     eng.close()
     assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
     assert out[False][3] == out[True][3] and np.array_equal(out[False][2], out[True][2])
+    # short sequences use the latency form (one quad per pose): the same fusion, 16 poses per wave
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    e2 = SweepEngine(Cfg())
+    e2.upload(zz, odo, u)
+    res = {}
+    for fuse in (False, True):
+        e2.set_colour_fusion(fuse)
+        e2.set_state(init["map_init"], init["x_init"], odo[:, 0], 11)
+        e2.enable_timing(True)
+        for _ in range(3):
+            e2.sweep_device("redblack")
+        assert e2.kernel_times()["k_solve"][1] == (3 if fuse else 6)
+        e2.enable_timing(False)
+        res[fuse] = e2.get_state()
+    e2.close()
+    assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1])
