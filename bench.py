@@ -46,7 +46,8 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True):
     the kernel must read or write once, no re-reads.  nnz = kept beams, E = (pose, landmark)
     entries, nloc = poses of the shard, L = landmark capacity; hier = the hierarchical entry
     pipeline ran (k_pose_moments then reads the staged entries and the prefixes itself)."""
-    nchunks = (nloc + 63) // 64
+    ch = 64 if nloc >= 65536 else (32 if nloc >= 16384 else 16)   # poses per chunk (icm_api.hip)
+    nchunks = (nloc + ch - 1) // ch
     group = (nchunks + 63) // 64
     nsuper = (nchunks + group - 1) // max(group, 1)
     per_sweep = {

@@ -103,7 +103,7 @@ struct icm_handle {
     // hierarchical running sums (k_chunk_l1 .. k_rec_push): records = chunks x kT1 slots
     DevBuf<int> rec_label;
     DevBuf<double> rec_s, rec_off, ms;   // [3][nrec], [3][nrec], [3][nsuper][L]
-    int nchunks = 0, chunk_group = 1, nsuper = 0;
+    int nchunks = 0, chunk_poses = 64, chunk_group = 1, nsuper = 0;
     DevBuf<int> solve_flags;  // per-wave completion flags of the fused red-black solve (+1: error word)
     int solve_epoch = 0;
     bool fused_used = false;
@@ -343,7 +343,9 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->counts_new.reserve(L));
     HIPCHK(h, h->mapx.reserve(L)); HIPCHK(h, h->mapy.reserve(L));
     HIPCHK(h, h->g_cell.reserve(8 * L + 4096 + 2));
-    h->nchunks = (nloc + kCH - 1) / kCH;
+    // poses per chunk: a chunk is one wave's serial work, so short sequences take short chunks
+    h->chunk_poses = nloc >= 65536 ? 64 : (nloc >= 16384 ? 32 : 16);
+    h->nchunks = (nloc + h->chunk_poses - 1) / h->chunk_poses;
     h->chunk_group = (h->nchunks + kMaxSuper - 1) / kMaxSuper;
     h->nsuper = (h->nchunks + h->chunk_group - 1) / h->chunk_group;
     {
@@ -590,10 +592,13 @@ int icm_sweep_local(icm_handle* h) {
         TIMED(h, KID_SCAN, (k_scan_tiles<<<ntiles, kBlock, 0, h->stream>>>(h->nent.p, h->isnew.p, h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc)));
         TIMED(h, KID_SCAN, (k_scan_fix<<<ntiles, kBlock, 0, h->stream>>>(h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc, ntiles)));
         if (hier) {  // launched before the host looks at the counts: one synchronisation per sweep
-            TIMED(h, KID_CHUNK_L1, (k_chunk_l1<<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(
-                h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->boff.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0,
-                h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, pre + 2 * nzs, h->e_val.p,
-                h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave)));
+#define CHUNK_L1(CH)                                                                                                   \
+    TIMED(h, KID_CHUNK_L1, (k_chunk_l1<CH><<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(                          \
+        h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->boff.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0,   \
+        h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, pre + 2 * nzs, h->e_val.p,                     \
+        h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave)))
+            if (h->chunk_poses == 64) CHUNK_L1(64); else if (h->chunk_poses == 32) CHUNK_L1(32); else CHUNK_L1(16);
+#undef CHUNK_L1
             if (!h->ms_clean) HIPCHK(h, hipMemsetAsync(ms, 0, 3 * msn * sizeof(double), h->stream));
             h->ms_clean = false;
             TIMED(h, KID_CHUNK_L2, (k_chunk_l2<<<h->nsuper, kT1, 0, h->stream>>>(

@@ -942,7 +942,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_prefix(const double* __restric
 // (SURVEY Appendix A.3/A.6 phase B): a prefix, in time, of the per-landmark sums.  Consecutive
 // poses see nearly the same landmarks, so the prefix is formed level by level instead of
 // sorting all entries by landmark:
-//   k_chunk_l1   one WAVE per chunk of kCH consecutive poses walks its poses in time order;
+//   k_chunk_l1   one WAVE per chunk of 64 (32, 16) consecutive poses walks its poses in time order;
 //                a small LDS table keyed by landmark holds the running sums of the chunk:
 //                every entry gets its prefix inside the chunk, every (chunk, landmark) RECORD
 //                the chunk's total.  Record r = chunk * kT1 + table slot (unused slots empty).
@@ -959,7 +959,8 @@ __global__ __launch_bounds__(kBlock) void k_stats_prefix(const double* __restric
 // raises flags[1]; the host then runs the sort-based pipeline (k_compact .. k_lm_scan), which
 // has no such limits.
 // ---------------------------------------------------------------------------------------
-constexpr int kCH = 64;          // poses per chunk (= lanes: lane p holds pose p's header)
+constexpr int kCHMax = 64;       // poses per chunk: 64, 32 or 16 (lane p holds pose p's header); short
+                                 // sequences use short chunks -- a chunk is ONE wave's serial work
 constexpr int kT1 = 256;         // slots of a chunk table
 constexpr int kT2 = 2048;        // slots of a superchunk table
 constexpr int kT2Cap = 1536;
@@ -1025,6 +1026,7 @@ __device__ __forceinline__ void load_group(EntryGroup& g, int p0, int lane, int 
     }
 }
 
+template <int kCH>
 __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ x, const double* __restrict__ x0,
                                                      int t_begin, int nloc, int nchunks, const int* __restrict__ boff,
                                                      const int* __restrict__ nent, const int* __restrict__ ent_off,
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
     const int tl = c * kCH + lane;
     int j0 = 0, n = 0, e0 = 0, nr = 0;
     double px = 0.0, py = 0.0, th = 0.0;
-    if (tl < nloc) {
+    if (lane < kCH && tl < nloc) {
         j0 = boff[tl];
         n = nent[tl];
         e0 = ent_off[tl];
