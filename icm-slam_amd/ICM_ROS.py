@@ -69,6 +69,24 @@ class ICM_ROS(ROS):
         self._seq_key = None
         return self.mediciones, self.odometria, self.u
 
+    def load_messages(self, lidar, odometria):
+        """Sequence from the buffers of the two topic subscribers (`Lidar`, `Odometria` of
+        sensors_definitions.py, filled live over rosbridge or by matlab2ros.replay): samples are
+        paired by sequence number, scans become the columns of `mediciones`, poses and twists the
+        columns of `odometria` / `u` -- the arrays `inicializar_online` accumulates
+        (reference scripts/ICM_ROS.py:66-93) and `load_data()` reads from a file."""
+        scans = {m['seq']: m['data'] for m in lidar.msgs}
+        odos = {m['seq']: m['data'] for m in odometria.msgs}
+        seqs = sorted(set(scans) & set(odos))
+        if not seqs:
+            raise ValueError("load_messages: no sample with both a scan and an odometry message")
+        self.mediciones = np.ascontiguousarray(np.hstack([scans[k].reshape(-1, 1) for k in seqs]), dtype=np.float64)
+        self.odometria = np.ascontiguousarray(np.hstack([odos[k]['odo'].reshape(3, 1) for k in seqs]), dtype=np.float64)
+        self.u = np.ascontiguousarray(np.hstack([odos[k]['u'].reshape(2, 1) for k in seqs]), dtype=np.float64)
+        self.x0 = np.array([self.odometria[:, 0]]).T
+        self._seq_key = None
+        return self.mediciones, self.odometria, self.u
+
     def set_initial_state(self, positions, mapa, cant_obs_i=None):
         """Install the result of an initialisation pass: poses (3,T) and landmark map (2,K)
         (what `inicializar_online` leaves in `self.positions` / `self.mapa_viejo`,

@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from util import Cfg, ROOT, gold
+from util import Cfg, ROOT, dataset, gold
 
 
 def test_library_exports_every_declared_symbol():
@@ -138,3 +138,32 @@ def test_host_first_scan_clustering_equals_scipy():
     assert np.array_equal(cluster_first_scan(np.array([[1.0, 2.0]]), 1.0), [0])
     s = gold("init_pass.npz")
     assert set(s["labels_scan0"]) == {0, 1}
+
+
+def test_message_replay_round_trip_through_the_topic_parsers():
+    """matlab2ros.replay (counterpart of the reference's 10 Hz publisher) -> Lidar / Odometria
+    callbacks -> ICM_ROS.load_messages reproduces what load_data() reads from the file: ranges
+    inflated by the trunk radius and clipped, poses, twists.  (The LaserScan parser keeps 180 of
+    the dataset's 181 beams, reference scripts/sensors_definitions.py:23-29.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "icm-slam_amd"))
+    from ICM_SLAM_tools import ConfigICM
+    from ICM_ROS import ICM_ROS
+    from sensors_definitions import Lidar, Odometria
+    from matlab2ros.replay import replay, stamp_of
+    d = gold("data_IJAC2018.npz")
+    T = 300
+    cfg = ConfigICM(os.path.join(ROOT, "icm-slam_amd", "config_default.yaml"))
+    lidar, odo = Lidar(config=cfg), Odometria(config=cfg)
+    n = replay(d["observations"][:, :T], d["odometry"][:, :T], d["velocities"][:, :T], lidar.callback, odo.callback)
+    assert n == T and len(lidar.msgs) == T and len(odo.msgs) == T
+    assert stamp_of(25) == {"secs": 2, "nsecs": 500000000}
+    icm = ICM_ROS.__new__(ICM_ROS)      # (no GPU needed for the loaders)
+    icm.config = cfg
+    z, od, u = icm.load_messages(lidar, odo)
+    zz, odo_ref, u_ref = dataset()
+    assert z.shape == (180, T)
+    assert np.array_equal(z, zz[:180, :T])
+    assert np.array_equal(od[:2], odo_ref[:2, :T]) and np.array_equal(u, u_ref[:, :T])
+    dyaw = np.abs(np.angle(np.exp(1j * (od[2] - odo_ref[2, :T]))))
+    assert dyaw.max() <= 1e-14          # yaw through the quaternion and back
