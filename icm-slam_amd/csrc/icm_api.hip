@@ -104,6 +104,17 @@ struct icm_handle {
     DevBuf<int> rec_label;
     DevBuf<double> rec_s, rec_off, ms;   // [3][nrec], [3][nrec], [3][nsuper][L]
     int nchunks = 0, chunk_poses = 64, chunk_group = 1, nsuper = 0;
+    // icm_snapshot_state / icm_restore_state: device copy of the sweep state (poses, map, search structures)
+    struct Snapshot {
+        DevBuf<double> x, mapx, mapy, counts_new;
+        DevBuf<int> g_cell;
+        DevBuf<LmRec> g_lm;
+        DevBuf<NeighRec> g_nb;
+        DevBuf<GridParams> gpar;
+        std::vector<double> h_map, h_counts;
+        int64_t K = 0, lact = 0;
+        bool h_map_valid = true, valid = false;
+    } snap;
     DevBuf<int> solve_flags;  // per-wave completion flags of the fused red-black solve (+1: error word)
     int solve_epoch = 0;
     bool fused_used = false;
@@ -248,6 +259,8 @@ int icm_destroy(icm_handle* h) {
     h->skey.release();
     h->sort_tmp.release();
     h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release();
+    h->snap.x.release(); h->snap.mapx.release(); h->snap.mapy.release(); h->snap.counts_new.release();
+    h->snap.g_cell.release(); h->snap.g_lm.release(); h->snap.g_nb.release(); h->snap.gpar.release();
     if (h->pin_i) (void)hipHostFree(h->pin_i);
     if (h->pin_d) (void)hipHostFree(h->pin_d);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -291,6 +304,7 @@ int icm_upload(icm_handle* h, const double* ranges, const double* odo, const dou
     HIPCHK(h, hipMemcpyAsync(h->u.p, u, 2 * (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->uploaded = true;
+    h->snap.valid = false;
     h->prefiltered = false;
     h->have_state = false;
     return ICM_OK;
@@ -874,6 +888,53 @@ static int sync_host_map(icm_handle* h) {
     }
     HIPCHK(h, hipMemcpy(h->h_counts.data(), h->counts_new.p, L * sizeof(double), hipMemcpyDeviceToHost));
     h->h_map_valid = true;
+    return ICM_OK;
+}
+
+// Device-side copy of everything a sweep reads and replaces: poses, mapa_viejo with its counters
+// and search structures.  icm_restore_state puts it back with a few device-to-device copies (no
+// host round trip), e.g. to run many sweeps from the same start.
+int icm_snapshot_state(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_snapshot_state: no state (icm_set_state)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t T = (size_t)h->T, L = (size_t)h->cfg.L, nc = (size_t)h->max_cells;
+    icm_handle::Snapshot& sn = h->snap;
+    HIPCHK(h, sn.x.reserve(3 * T)); HIPCHK(h, sn.mapx.reserve(L)); HIPCHK(h, sn.mapy.reserve(L)); HIPCHK(h, sn.counts_new.reserve(L));
+    HIPCHK(h, sn.g_cell.reserve(nc + 2)); HIPCHK(h, sn.g_lm.reserve(L)); HIPCHK(h, sn.g_nb.reserve(nc)); HIPCHK(h, sn.gpar.reserve(1));
+    hipStream_t st = h->stream;
+    HIPCHK(h, hipMemcpyAsync(sn.x.p, h->x, 3 * T * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(sn.mapx.p, h->mapx.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(sn.mapy.p, h->mapy.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(sn.counts_new.p, h->counts_new.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(sn.g_cell.p, h->g_cell.p, (nc + 2) * sizeof(int), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(sn.g_lm.p, h->g_lm.p, L * sizeof(LmRec), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(sn.g_nb.p, h->g_nb.p, nc * sizeof(NeighRec), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(sn.gpar.p, h->gpar.p, sizeof(GridParams), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    sn.h_map = h->h_map; sn.h_counts = h->h_counts;
+    sn.K = h->K; sn.lact = h->lact; sn.h_map_valid = h->h_map_valid;
+    sn.valid = true;
+    return ICM_OK;
+}
+
+int icm_restore_state(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    icm_handle::Snapshot& sn = h->snap;
+    const size_t T = (size_t)h->T, L = (size_t)h->cfg.L, nc = (size_t)h->max_cells;
+    if (!sn.valid || sn.x.cap < 3 * T || sn.g_nb.cap < nc) FAIL(h, ICM_ERR_ARG, "icm_restore_state: no snapshot of this sequence (icm_snapshot_state)");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;   // stream-ordered behind the last sweep: no synchronisation needed
+    HIPCHK(h, hipMemcpyAsync(h->x, sn.x.p, 3 * T * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->mapx.p, sn.mapx.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->mapy.p, sn.mapy.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->counts_new.p, sn.counts_new.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->g_cell.p, sn.g_cell.p, (nc + 2) * sizeof(int), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->g_lm.p, sn.g_lm.p, L * sizeof(LmRec), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->g_nb.p, sn.g_nb.p, nc * sizeof(NeighRec), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->gpar.p, sn.gpar.p, sizeof(GridParams), hipMemcpyDeviceToDevice, st));
+    h->h_map = sn.h_map; h->h_counts = sn.h_counts;
+    h->K = sn.K; h->lact = sn.lact; h->h_map_valid = sn.h_map_valid;
     return ICM_OK;
 }
 

@@ -70,6 +70,8 @@ SIGNATURES = {
     "icm_get_solve_diag": (C.c_int, [_H, _dp]),
     "icm_set_gpu_filtrar": (C.c_int, [_H, C.c_int]),
     "icm_set_solve_lanes": (C.c_int, [_H, C.c_int]),
+    "icm_snapshot_state": (C.c_int, [_H]),
+    "icm_restore_state": (C.c_int, [_H]),
     "icm_set_colour_fusion": (C.c_int, [_H, C.c_int]),
     "icm_set_entry_path": (C.c_int, [_H, C.c_int]),
     "icm_get_entry_path": (C.c_int, [_H]),

@@ -343,6 +343,14 @@ class SweepEngine:
         """-1 automatic, 0 one lane per pose, 1 one quad per pose (latency form)."""
         self._chk(self.lib.icm_set_solve_lanes(self.h, int(mode)))
 
+    def snapshot_state(self):
+        """Keep a device-side copy of the current sweep state (poses, map, search structures)."""
+        self._chk(self.lib.icm_snapshot_state(self.h))
+
+    def restore_state(self):
+        """Back to the snapshot (device-to-device copies, stream-ordered)."""
+        self._chk(self.lib.icm_restore_state(self.h))
+
     def set_colour_fusion(self, on):
         """True (default): both colours of an unsharded red-black sweep in one launch."""
         self._chk(self.lib.icm_set_colour_fusion(self.h, int(bool(on))))

@@ -104,6 +104,13 @@ int icm_set_state(icm_handle *h, const double *x, const double *x0, const double
 int icm_sweep_device(icm_handle *h, int schedule);
 int icm_get_state(icm_handle *h, double *x, double *map_out, double *counts_out, int64_t *K_out);
 
+/* Snapshot of the sweep state held on the device (poses, mapa_viejo with its counters and search
+ * structures) and its restoration by device-to-device copies, stream-ordered, no host round trip:
+ * re-running sweeps from the same start (benchmarks, A/B comparisons of the knobs below).  A
+ * snapshot belongs to the uploaded sequence; icm_upload discards it. */
+int icm_snapshot_state(icm_handle *h);
+int icm_restore_state(icm_handle *h);
+
 /* ---- sharded sweep: the same sweep cut at the one point where ranks exchange data ------ */
 /* Bind the exchange buffers (device memory owned by the caller, e.g. torch tensors):
  *   stats_all [world * icm_stats_stride()] doubles: rank r's landmark sufficient

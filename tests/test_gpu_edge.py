@@ -406,3 +406,51 @@ def test_fused_two_colour_launch_is_bit_identical():
         res[fuse] = e2.get_state()
     e2.close()
     assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1])
+
+
+def test_snapshot_and_restore_on_the_device():
+    """icm_snapshot_state / icm_restore_state: sweeps re-run from a snapshot give the same bits,
+    whether the snapshot was taken right after icm_set_state (host-built search grid) or between
+    sweeps (map, counters and grid produced on the GPU by the fused Mapa.filtrar)."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    wl = make_workload(1900, 100, 180)
+    eng = SweepEngine(ConfigICM(D=wl.config))
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    eng.set_state(wl.map_init, wl.x_init, wl.x0)
+    eng.snapshot_state()
+    runs = []
+    for _ in range(2):
+        for _ in range(3):
+            eng.sweep_device("redblack")
+        runs.append(eng.get_state())
+        eng.restore_state()
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)
+    # snapshot in the middle of a run
+    for _ in range(2):
+        eng.sweep_device("redblack")
+    eng.snapshot_state()
+    mid = eng.get_state()
+    for _ in range(2):
+        eng.sweep_device("redblack")
+    after = eng.get_state()
+    eng.restore_state()
+    back = eng.get_state()
+    for a, b in zip(mid, back):
+        assert np.array_equal(a, b)
+    for _ in range(2):
+        eng.sweep_device("redblack")
+    again = eng.get_state()
+    eng.close()
+    for a, b in zip(after, again):
+        assert np.array_equal(a, b)
+    # a snapshot does not survive a new upload
+    e2 = SweepEngine(ConfigICM(D=wl.config))
+    e2.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    e2.set_state(wl.map_init, wl.x_init, wl.x0)
+    from icmslam_hip import IcmError
+    with pytest.raises((IcmError, ValueError, RuntimeError)):
+        e2.restore_state()
+    e2.close()
