@@ -187,7 +187,7 @@ def main():
     # entry pipelines).  So that ANY --steps measures the same work per step, the state is rewound
     # to the initial one every RESET_EVERY sweeps by a device-side copy (icm_restore_state, ~20 MB
     # device-to-device, stream-ordered, ~10 us) -- inside the timed region, on every rank.
-    RESET_EVERY = 16
+    RESET_EVERY = 12
     eng.snapshot_state()
     inner_step, nsweeps = step, [0]
 
