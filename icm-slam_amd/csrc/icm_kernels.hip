@@ -611,26 +611,15 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     int nent = 0;
     bool overflow = false;
     __builtin_amdgcn_wave_barrier();
-    // the beams of chunk c+1 are requested before chunk c is searched (one round trip hidden)
-    double nbx = 0.0, nby = 0.0;
-    if (j0 + lane < j1) {
-        nbx = bx[j0 + lane];
-        nby = by[j0 + lane];
-    }
     for (int base = j0; base < j1 && !overflow; base += kWave) {
         const int j = base + lane;
         const bool valid = j < j1;
         const int cn = min(kWave, j1 - base);
         int lab = -2;
-        const double bxx = nbx, byy = nby;
-        if (j + kWave < j1) {
-            nbx = bx[j + kWave];
-            nby = by[j + kWave];
-        } else {
-            nbx = 0.0;
-            nby = 0.0;
-        }
+        double bxx = 0.0, byy = 0.0;
         if (valid) {
+            bxx = bx[j];
+            byy = by[j];
             if (PRELABEL) {
                 lab = label[j];
             } else {
