@@ -4,6 +4,7 @@
 // solves.  Host round trips per sweep: one 12-byte read-back (entry / new-landmark counts --
 // rocPRIM needs the sort size) and one 16-byte read-back of the filter result; Mapa.filtrar
 // falls back to the host routine only when landmarks have to be merged.
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -133,7 +134,7 @@ struct icm_handle {
     int hash_slots = 128;  // k_assoc_group's per-pose table; grows to 256 on overflow
     int solve_quad = -1;   // -1 automatic, 0 one lane per pose, 1 one quad per pose
     int form = 0;  // 0 moments (lane per pose), 1 per beam, 2 per entry (wave per pose)
-    int *pin_i = nullptr;
+    int *pin_i = nullptr, *pin_i_dev = nullptr;   // pinned host words and their device-side address
     double* pin_d = nullptr;  // pinned staging: raw map download (3L)
     std::vector<double> h_yraw, h_cntraw;
 
@@ -217,7 +218,8 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
         (e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->ev_map, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_i), 64 * sizeof(int))) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_i), 64 * sizeof(int), hipHostMallocMapped)) != hipSuccess ||
+        (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_i_dev), h->pin_i, 0)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_d), (size_t)(3 * cfg->L + 16 + 64) * sizeof(double))) != hipSuccess) {
         g_create_err = std::string("icm_create: ") + hipGetErrorString(e);
         delete h;
@@ -794,8 +796,11 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         ++h->solve_epoch;   // (flags hold the epoch of the launch that set them: no reset between launches)
         h->fused_used = true;
         h->pin_i[4] = 0;   // (pinned host memory, mapped into the device: a wave that gives up waiting writes 1 here)
-        if (quad) TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->pin_i + 4)));
-        else TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->pin_i + 4)));
+        // test hook for the give-up path: the odd waves publish a stale epoch, every even wave times out
+        static const bool stall = std::getenv("ICMSLAM_TEST_STALL_FUSED") != nullptr;
+        const int publish = stall ? h->solve_epoch - 1 : h->solve_epoch;
+        if (quad) TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, publish, h->pin_i_dev + 4)));
+        else TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, publish, h->pin_i_dev + 4)));
     } else if (schedule == ICM_SCHEDULE_REDBLACK) {
         const int nw = (int)(h->nloc / 2 + 1);
         for (int col = 1; col >= 0; --col) {

@@ -1839,7 +1839,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
 // QUAD: the latency form (one DPP quad per pose, 16 poses per wave) with the same dependency rule.
 template <bool QUAD>
 __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, int* __restrict__ flags, int epoch,
-                                                          int* __restrict__ err) {
+                                                          int publish, int* __restrict__ err) {
     constexpr int PPW = QUAD ? kWave / 4 : kWave;   // poses per wave
     const int lane = lane_id();
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -1854,7 +1854,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, i
                 int spins = 0;
                 while (__hip_atomic_load(&flags[wv + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 24)) {
+                    if (++spins > (1 << 22)) {   // (seconds: a legitimate wait is at most the length of the launch)
                         *reinterpret_cast<volatile int*>(err) = 1;   // (host-pinned word)
                         break;
                     }
@@ -1878,7 +1878,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&flags[wv], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(&flags[wv], publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (= epoch)
     }
 }
 

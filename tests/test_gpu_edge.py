@@ -1,8 +1,10 @@
 """Edge cases and size-independent properties of the HIP sweep."""
+import os
+
 import numpy as np
 import pytest
 
-from util import Cfg, dataset, gold
+from util import Cfg, ROOT, dataset, gold
 
 pytestmark = pytest.mark.gpu
 
@@ -454,3 +456,40 @@ def test_snapshot_and_restore_on_the_device():
     with pytest.raises((IcmError, ValueError, RuntimeError)):
         e2.restore_state()
     e2.close()
+
+
+def test_fused_solve_gives_up_instead_of_hanging():
+    """Safety net of the one-launch red-black solve: if the flags an even wave waits for never
+    arrive (forced here by a test hook that makes the odd waves publish a stale epoch), the waves
+    stop polling after a bounded number of tries, the grid drains and the sweep reports an error --
+    the GPU is never left with a spinning kernel."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, time
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from util import Cfg, dataset, gold
+from icmslam_hip import SweepEngine, IcmError
+zz, odo, u = dataset()
+init = gold("init_pass.npz")
+eng = SweepEngine(Cfg())
+eng.upload(zz, odo, u)
+eng.set_state(init["map_init"], init["x_init"], odo[:, 0], 11)
+t0 = time.time()
+try:
+    eng.sweep_device("redblack")
+    print("NO-ERROR")
+except IcmError as e:
+    print("GAVE-UP after %%.1f s: %%s" %% (time.time() - t0, e))
+eng.set_colour_fusion(False)          # the handle is still usable with one launch per colour
+eng.set_state(init["map_init"], init["x_init"], odo[:, 0], 11)
+eng.sweep_device("redblack")
+print("RECOVERED", np.isfinite(eng.get_state()[0]).all())
+""" % (os.path.join(ROOT, "icm-slam_amd"), ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, ICMSLAM_TEST_STALL_FUSED="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0
+    assert "GAVE-UP" in out.stdout and "timed out" in out.stdout
+    assert "RECOVERED True" in out.stdout
