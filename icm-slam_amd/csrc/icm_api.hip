@@ -611,7 +611,8 @@ int icm_sweep_local(icm_handle* h) {
 #define CHUNK_L1(CH)                                                                                                   \
     TIMED(h, KID_CHUNK_L1, (k_chunk_l1<CH><<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(                          \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->boff.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0,   \
-        h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, pre + 2 * nzs, h->e_val.p,                     \
+        h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, reinterpret_cast<unsigned*>(pre + 2 * nzs),        \
+        reinterpret_cast<unsigned char*>(h->e_val.p),                                                                   \
         h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave)))
             if (h->chunk_poses == 64) CHUNK_L1(64); else if (h->chunk_poses == 32) CHUNK_L1(32); else CHUNK_L1(16);
 #undef CHUNK_L1
@@ -704,7 +705,8 @@ int icm_sweep_targets(icm_handle* h) {
             ro, ro + nrec, ro + 2 * (size_t)nrec)));
         TIMED(h, KID_POSE_MOMENTS, (k_pose_moments_h<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(
             h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p,
-            pre, pre + nzs, pre + 2 * nzs, h->e_val.p, ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr)));
+            pre, pre + nzs, reinterpret_cast<const unsigned*>(pre + 2 * nzs), reinterpret_cast<const unsigned char*>(h->e_val.p), h->chunk_poses,
+            ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr)));
     } else if (h->world > 1) {
         TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
         TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, h->off_sx.p, h->off_sy.p, h->off_n.p, h->tgt.p, nullptr, nullptr, nullptr)));

@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                                                      const int* __restrict__ st_label, const int* __restrict__ st_k,
                                                      const double* __restrict__ st_sbx, const double* __restrict__ st_sby,
                                                      double* __restrict__ pre_x, double* __restrict__ pre_y,
-                                                     double* __restrict__ pre_n, int* __restrict__ e_rec,
+                                                     unsigned* __restrict__ pre_n, unsigned char* __restrict__ e_rec,
                                                      int* __restrict__ rec_label, double* __restrict__ rec_sx,
                                                      double* __restrict__ rec_sy, double* __restrict__ rec_n,
                                                      int* __restrict__ flags, size_t dump) {
@@ -1130,8 +1130,8 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                 const size_t o = act ? (size_t)(ep + lane) : dump + lane;
                 pre_x[o] = ax;
                 pre_y[o] = ay;
-                pre_n[o] = an;
-                e_rec[o] = c * kT1 + sl;
+                pre_n[o] = (unsigned)an;          // (a count of beams: exact, < 2^32 -- checked at upload)
+                e_rec[o] = (unsigned char)sl;     // slot; the chunk follows from the pose
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1698,7 +1698,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
                                                            const double* __restrict__ st_sby,
                                                            const double* __restrict__ pose_s2,
                                                            const double* __restrict__ pre_x, const double* __restrict__ pre_y,
-                                                           const double* __restrict__ pre_n, const int* __restrict__ e_rec,
+                                                           const unsigned* __restrict__ pre_n, const unsigned char* __restrict__ e_rec, int chunk_poses,
                                                            const double* __restrict__ off_x, const double* __restrict__ off_y,
                                                            const double* __restrict__ off_n, double* __restrict__ pose_m,
                                                            double2* __restrict__ tgt_out) {
@@ -1721,8 +1721,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
     double mxx = 0.0, mxy = 0.0, myy = 0.0;
     for (int q = sub; q < n; q += 16) {
         const double k = (double)st_k[j0 + q], sbx = st_sbx[j0 + q], sby = st_sby[j0 + q];
-        const int r = e_rec[e0 + q];
-        const double sx = off_x[r] + pre_x[e0 + q], sy = off_y[r] + pre_y[e0 + q], sn = off_n[r] + pre_n[e0 + q];
+        const int r = (tl / chunk_poses) * kT1 + (int)e_rec[e0 + q];
+        const double sx = off_x[r] + pre_x[e0 + q], sy = off_y[r] + pre_y[e0 + q], sn = off_n[r] + (double)pre_n[e0 + q];
         const double tx = sx / sn, ty = sy / sn;
         if (tgt_out) tgt_out[e0 + q] = make_double2(tx, ty);   // association dump (icm_set_debug)
         const double wx = (ct * sbx - st * sby) / k, wy = (st * sbx + ct * sby) / k;
