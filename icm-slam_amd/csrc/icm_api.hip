@@ -486,6 +486,18 @@ static int edge_last(const icm_handle* h) {
     return (int)std::min<int64_t>(std::max<int64_t>(h->t_begin + h->nloc - 1, 0), std::max<int64_t>(h->T - 1, 0));
 }
 
+// Call after the main stream has been synchronised: did an even wave of the last fused red-black
+// solve give up waiting for its odd neighbours?
+static int check_fused(icm_handle* h) {
+    if (!h->fused_used) return ICM_OK;
+    h->fused_used = false;
+    if (h->pin_i[4]) {
+        h->pin_i[4] = 0;
+        FAIL(h, ICM_ERR_HIP, "fused red-black solve: a wave timed out waiting for its neighbours (icm_set_colour_fusion(h, 0) selects two launches)");
+    }
+    return ICM_OK;
+}
+
 // this rank's slot of the landmark statistics: the send buffer if one is bound
 static double* stats_slot(icm_handle* h) {
     return h->stats_send ? h->stats_send : h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h);
@@ -632,6 +644,10 @@ int icm_sweep_local(icm_handle* h) {
             HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        {
+            int rcf = check_fused(h);   // (the previous sweep's solves are behind this synchronisation too)
+            if (rcf) return rcf;
+        }
         if (h->pin_i[2] && h->hash_slots == 128) {  // a scan with > 96 distinct landmarks: use the larger table from now on
             h->hash_slots = 256;
             HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
@@ -856,17 +872,17 @@ int icm_sweep_finish(icm_handle* h) {
         // (k_filtrar_grid); the refined map becomes the next mapa_viejo (scripts/ICM_ROS.py:311)
         h->K = h->lact = h->pin_i[8];
         h->h_map_valid = false;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (h->fused_used) {  // did an even wave give up waiting for its odd neighbours?
-            h->fused_used = false;
-            if (h->pin_i[4]) FAIL(h, ICM_ERR_HIP, "fused red-black solve: a wave timed out waiting for its neighbours (icm_set_colour_fusion(h, 0) selects two launches)");
-        }
+        // No wait for the solves here: everything the host needs (raw map, filtrar result) came
+        // over the side stream, and whatever is queued next on the main stream is ordered behind
+        // them -- the next sweep's phase A starts the moment the last solve ends.  (Readers of x
+        // synchronise themselves; a fused solve that gave up is reported at the next
+        // synchronisation of the main stream.)
         return ICM_OK;
     }
-    if (h->fused_used) {
-        h->fused_used = false;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (h->pin_i[4]) FAIL(h, ICM_ERR_HIP, "fused red-black solve: a wave timed out waiting for its neighbours (icm_set_colour_fusion(h, 0) selects two launches)");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    {
+        int rcf = check_fused(h);
+        if (rcf) return rcf;
     }
     std::vector<double> yo(2 * L), co(L);
     int64_t lact_new = 0;
@@ -966,6 +982,10 @@ int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out,
         std::vector<double> xt(3 * T);
         HIPCHK(h, hipMemcpyAsync(xt.data(), h->x, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        {
+            int rcf = check_fused(h);
+            if (rcf) return rcf;
+        }
         for (size_t t = 0; t < T; ++t) {
             x[t] = xt[3 * t];
             x[T + t] = xt[3 * t + 1];

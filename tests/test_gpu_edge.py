@@ -478,7 +478,8 @@ eng.upload(zz, odo, u)
 eng.set_state(init["map_init"], init["x_init"], odo[:, 0], 11)
 t0 = time.time()
 try:
-    eng.sweep_device("redblack")
+    eng.sweep_device("redblack")   # returns while the solves are still queued ...
+    eng.get_state()                # ... the give-up is reported at the next synchronisation
     print("NO-ERROR")
 except IcmError as e:
     print("GAVE-UP after %%.1f s: %%s" %% (time.time() - t0, e))
