@@ -225,6 +225,7 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
         delete h;
         return ICM_ERR_HIP;
     }
+    std::memset(h->pin_i, 0, 64 * sizeof(int));
     {   // exact squared gate: the largest double whose correctly rounded sqrt is <= dist_thr
         const double thr = cfg->dist_thr;
         double s2 = thr * thr;
