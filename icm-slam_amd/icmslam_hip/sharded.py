@@ -2,7 +2,8 @@
 xGMI) for the two exchanges a sweep needs.
 
 Partition: contiguous pose blocks of `blk = ceil(T / world)` poses; rank r owns poses
-[r*blk, min((r+1)*blk, T)).  Scans live only on their owner; odometry, velocities, the pose
+[r*blk, min((r+1)*blk, T)) -- every rank must own at least one pose (icm_upload refuses an empty
+shard).  Scans live only on their owner; odometry, velocities, the pose
 array and the landmark table are replicated (they are KB..MB).
 
 Per sweep:

@@ -26,7 +26,7 @@ def _single(wl, cfg, sweeps):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 7])      # 7: shards of 272 poses and a last one of 268
 def test_virtual_ranks_match_unsharded(world):
     import torch
     from icmslam_hip import SweepEngine
