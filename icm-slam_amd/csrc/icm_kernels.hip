@@ -1151,6 +1151,8 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
     if (overflow && lane == 0) flags[1] = 1;
 }
 
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Level 2: thread s of the workgroup <-> slot s of each chunk's record block.
 __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, const int* __restrict__ rec_label,
                                                   const double* __restrict__ rec_sx, const double* __restrict__ rec_sy,
@@ -1171,45 +1173,57 @@ __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, con
     if (tid == 0) used = 0;
     __syncthreads();
     const int c0 = sc * G, c1 = min(c0 + G, nchunks);
-    int lab_n = kEmpty;
-    double vx_n = 0.0, vy_n = 0.0, vn_n = 0.0;
-    if (c0 < c1) {
-        const size_t r = (size_t)c0 * kT1 + tid;
-        lab_n = rec_label[r];
-        vx_n = rec_sx[r];
-        vy_n = rec_sy[r];
-        vn_n = rec_n[r];
-    }
+    // The records of the next kAhead chunks are in flight while one chunk is folded in.  Loads and
+    // stores are issued by every thread in every step (clamped index / the record's own, unused
+    // slot), never under a branch, so that the compiler can count them and wait (vmcnt(N)) for
+    // exactly the chunk it is about to use instead of draining the queue.
+    constexpr int kAhead = 3;
+    int lab_q[kAhead];
+    double vx_q[kAhead], vy_q[kAhead], vn_q[kAhead];
+    auto fetch = [&](int q, int cn) {   // records of chunk cn (clamped; empty beyond the superchunk) into queue slot q
+        const size_t r = (size_t)min(cn, max(c1 - 1, c0)) * kT1 + tid;
+        const int l = rec_label[r];
+        lab_q[q] = cn < c1 ? l : kEmpty;
+        vx_q[q] = rec_sx[r];
+        vy_q[q] = rec_sy[r];
+        vn_q[q] = rec_n[r];
+    };
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) fetch(q, c0 + q);
     bool overflow = false;
-    for (int c = c0; c < c1; ++c) {
-        const int lab = lab_n;
-        const double vx = vx_n, vy = vy_n, vn = vn_n;
-        if (c + 1 < c1) {  // next chunk's records are in flight while this one is folded in
-            const size_t r = (size_t)(c + 1) * kT1 + tid;
-            lab_n = rec_label[r];
-            vx_n = rec_sx[r];
-            vy_n = rec_sy[r];
-            vn_n = rec_n[r];
-        }
-        if (lab != kEmpty) {
-            bool inserted;
-            const int slot = table_slot(key, kT2 - 1, 21, lab, inserted);
-            if (inserted) atomicAdd(&used, 1);
-            const double ox = sx[slot], oy = sy[slot], on = sn[slot];  // a landmark has one record per chunk
-            const size_t r = (size_t)c * kT1 + tid;
+    for (int cb = c0; cb < c1 && !overflow; cb += kAhead) {
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) {   // slot q holds chunk cb + q; it is refilled in place (no register shuffling)
+            const int c = cb + q;
+            if (c >= c1) break;
+            const int lab = lab_q[q];
+            const double vx = vx_q[q], vy = vy_q[q], vn = vn_q[q];
+            fetch(q, c + kAhead);
+            double ox = 0.0, oy = 0.0, on = 0.0;
+            if (lab != kEmpty) {
+                bool inserted;
+                const int slot = table_slot(key, kT2 - 1, 21, lab, inserted);
+                if (inserted) atomicAdd(&used, 1);
+                ox = sx[slot];   // a landmark has one record per chunk: no two threads meet in a slot
+                oy = sy[slot];
+                on = sn[slot];
+                sx[slot] = ox + vx;
+                sy[slot] = oy + vy;
+                sn[slot] = on + vn;
+            }
+            const size_t r = (size_t)c * kT1 + tid;   // (an empty record's slot is never read)
             off_x[r] = ox;
             off_y[r] = oy;
             off_n[r] = on;
-            sx[slot] = ox + vx;
-            sy[slot] = oy + vy;
-            sn[slot] = on + vn;
-        }
-        __syncthreads();
-        const int u = used;   // read between two barriers: the same value in every thread
-        __syncthreads();
-        if (u > kT2Cap) {
-            overflow = true;
-            break;
+            // workgroup barriers that wait for this wave's LDS traffic only: __syncthreads() would
+            // also drain the global loads in flight for the next chunks
+            lds_barrier();
+            const int u = used;   // read between two barriers: the same value in every thread
+            lds_barrier();
+            if (u > kT2Cap) {
+                overflow = true;
+                break;
+            }
         }
     }
     if (overflow) {
