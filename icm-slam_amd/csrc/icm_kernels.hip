@@ -646,26 +646,34 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         seg_step<0x142, 0xA>(dist > (lane & 15), ax, ay);   // run began in an earlier row
         seg_step<0x143, 0xC>(dist > (lane & 31), ax, ay);   // run began in rows 0-1
         const int nexthead = __shfl_down(head ? 1 : 0, 1, kWave);
-        const bool tail = valid && (lane == cn - 1 || nexthead);
+        bool tail = valid && (lane == cn - 1 || nexthead);
         // run tails claim / find the slot of their label
         int slot = 0;
-        bool inserted = false;
+        bool inserted = false, found = false;
         if (tail) {
             slot = (int)(((unsigned)lab * 2654435761u) >> kHashShift);
-            for (;;) {
+            // bounded: the table is checked against its 3/4 budget only between chunks, and one
+            // chunk can bring up to 64 new labels -- a full table must end the probe, not spin
+            for (int probes = 0; probes < kHash; ++probes) {
                 const int k = T.key[slot];
-                if (k == lab) break;
+                if (k == lab) {
+                    found = true;
+                    break;
+                }
                 if (k == kEmpty) {
                     const int old = atomicCAS(&T.key[slot], kEmpty, lab);
                     if (old == kEmpty || old == lab) {
                         inserted = old == kEmpty;
+                        found = true;
                         break;
                     }
                 }
                 slot = (slot + 1) & (kHash - 1);
             }
-            T.owner[slot] = lane;
+            if (found) T.owner[slot] = lane;
         }
+        if (__ballot(tail && !found) != 0ull) overflow = true;   // more distinct landmarks than slots
+        tail = tail && found;
         nent += __popcll(__ballot(inserted));
         __builtin_amdgcn_wave_barrier();
         const bool lose = tail && T.owner[slot] != lane;

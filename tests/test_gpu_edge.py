@@ -252,12 +252,13 @@ def test_s1_full_size_against_c_oracle():
     eng.close()
 
 
-def _dense_ring_case():
+def _dense_ring_case(grid=0.13, beams=360):
     """360 beams sweeping a ring of landmarks on a 0.13 m grid at ~3 m: neighbouring beams are
     ~0.05 m apart (so the isolated-beam filter keeps them) and hit a new landmark every couple
-    of beams -> far more than 96 distinct landmarks in one scan."""
+    of beams -> far more than 96 distinct landmarks in one scan.  `beams` < 360: only the first
+    `beams` rows see the ring (the rest read the maximum range and are dropped)."""
     B, T = 360, 6
-    g = np.arange(-30, 31) * 0.13
+    g = np.arange(-int(round(3.9 / grid)), int(round(3.9 / grid)) + 1) * grid
     gx, gy = np.meshgrid(g, g)
     lm = np.stack((gx.ravel(), gy.ravel()))
     rr = np.hypot(lm[0], lm[1])
@@ -272,6 +273,7 @@ def _dense_ring_case():
         p = x_true[:2, [t]] + 3.0 * np.stack((np.cos(a), np.sin(a)))
         j = np.argmin(np.hypot(lm[0][:, None] - p[0][None, :], lm[1][:, None] - p[1][None, :]), axis=0)
         scans[:, t] = np.hypot(lm[0, j] - x_true[0, t], lm[1, j] - x_true[1, t])
+        scans[beams:, t] = 10.0
     u = np.zeros((2, T))
     u[0] = 0.02
     cfgd = dict(N=1, deltat=0.1, L=4000, Q=[1, 1], R=[1, 1, 1], cte_odom=1.0, cota=1.0, dist_thr=0.09,
@@ -541,3 +543,36 @@ def test_rigid_motion_equivariance_at_s1_size():
     dm = d.max(axis=0)
     print("rigid motion: max|dx| %.3e, median %.3e, poses above 5e-3: %d of %d" % (dm.max(), np.median(dm), int((dm > 5e-3).sum()), T))
     assert np.median(dm) <= 2e-3 and dm.max() <= 0.2 and (dm > 5e-3).sum() <= T // 100
+
+
+def test_pose_table_filling_up_inside_one_fold_does_not_spin():
+    """~45 distinct landmarks per 64-beam chunk over three chunks: the 128-slot per-pose table is
+    within its 96-label budget after two chunks and would be over-full after the third.  The probe
+    loop is bounded, the sweep notices, relaunches phase A with 256 slots and matches the oracle
+    (an unbounded probe would spin on the full table)."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from oracle import c_oracle as co
+    lm, scans, x_true, u, cfgd = _dense_ring_case(grid=0.07, beams=224)
+    cfgd = dict(cfgd, dist_thr=0.055, L=14000)
+    cfg = ConfigICM(D=cfgd)
+    odo = x_true.copy()
+    T = x_true.shape[1]
+    keptc = co.prefilter(cfg, scans)
+    for debug in (False, True):
+        eng = SweepEngine(cfg)
+        eng.upload(scans, odo, u)
+        eng.set_debug(debug)
+        x = x_true.copy()
+        mo, cnt, K = eng.sweep(lm, x, x_true[:, 0], lm.shape[1], "redblack")
+        if debug:
+            lab = eng.association()[0]
+            off = eng.kept_beams()[0]
+            per_pose = [len(set(lab[off[t]:off[t + 1]])) for t in range(T)]
+            print("distinct labels per pose:", per_pose)
+            assert 128 < max(per_pose) <= 192
+        eng.close()
+        xc = x_true.copy()
+        mc, cntc, Kc, _ = co.sweep(cfg, keptc, u, odo, x_true[:, 0], lm, xc, lm.shape[1], "redblack")
+        assert K == Kc and np.array_equal(cnt, cntc) and np.abs(mo[:, :K] - mc).max() <= 1e-9
+        assert np.abs(x - xc).max() <= 1e-9
