@@ -34,7 +34,8 @@ void build_grid(const double* mx, const double* my, int64_t K, double dist_thr, 
     // landmark at distance <= dist_thr two cells away
     double cell = dist_thr > 0.0 ? dist_thr * (1.0 + 1e-9) : 1.0;
     const double max_cells = 8.0 * (double)K + 4096.0;
-    for (;;) {
+    g.nx = g.ny = 1;
+    for (int tries = 0; tries < 128; ++tries) {   // (bounded: a non-finite extent never fits)
         double nxd = std::floor((x1 - x0) / cell) + 1.0, nyd = std::floor((y1 - y0) / cell) + 1.0;
         if (nxd * nyd <= max_cells) {
             g.nx = (int)nxd;
@@ -42,6 +43,10 @@ void build_grid(const double* mx, const double* my, int64_t K, double dist_thr, 
             break;
         }
         cell *= 2.0;
+    }
+    if (!(x1 - x0 < HUGE_VAL) || !(y1 - y0 < HUGE_VAL)) {
+        x0 = y0 = 0.0;
+        cell = 1.0;
     }
     g.gx0 = x0;
     g.gy0 = y0;

@@ -1410,7 +1410,9 @@ __device__ void block_build_grid(const double* __restrict__ x, const double* __r
     double cell = cell_min > 0.0 ? cell_min : 1.0;
     int nx = 1, ny = 1;
     if (n > 0) {
-        for (;;) {
+        // (bounded: with a non-finite coordinate in the map the extent never fits; everything
+        // then lands in one cell instead of the workgroup spinning)
+        for (int tries = 0; tries < 128; ++tries) {
             const double nxd = floor((x1 - x0) / cell) + 1.0, nyd = floor((y1 - y0) / cell) + 1.0;
             if (nxd * nyd <= (double)max_cells) {
                 nx = (int)nxd;
@@ -1418,6 +1420,10 @@ __device__ void block_build_grid(const double* __restrict__ x, const double* __r
                 break;
             }
             cell *= 2.0;
+        }
+        if (!(x1 - x0 < __builtin_huge_val()) || !(y1 - y0 < __builtin_huge_val())) {
+            x0 = y0 = 0.0;
+            cell = 1.0;
         }
     } else {
         x0 = y0 = 0.0;

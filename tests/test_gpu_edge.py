@@ -576,3 +576,34 @@ def test_pose_table_filling_up_inside_one_fold_does_not_spin():
         mc, cntc, Kc, _ = co.sweep(cfg, keptc, u, odo, x_true[:, 0], lm, xc, lm.shape[1], "redblack")
         assert K == Kc and np.array_equal(cnt, cntc) and np.abs(mo[:, :K] - mc).max() <= 1e-9
         assert np.abs(x - xc).max() <= 1e-9
+
+
+@pytest.mark.timeout(120)
+def test_non_finite_inputs_do_not_hang():
+    """Garbage in (an infinite landmark coordinate, a NaN pose) may give garbage or an error out,
+    but every kernel and host loop must terminate: the grid-sizing loops are bounded, NaN world
+    points fall into cell 0 and are gated out."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    wl = make_workload(1900, 100, 180)
+    cfg = ConfigICM(D=wl.config)
+    for what in ("inf-landmark", "nan-pose", "inf-pose"):
+        m, x = wl.map_init.copy(), wl.x_init.copy()
+        if what == "inf-landmark":
+            m[0, 7] = np.inf
+        elif what == "nan-pose":
+            x[:, 500] = np.nan
+        else:
+            x[0, 900] = np.inf
+        eng = SweepEngine(cfg)
+        eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+        try:
+            eng.set_state(m, x, wl.x0)
+            for _ in range(3):
+                eng.sweep_device("redblack")
+            out = eng.get_state()
+            print(what, "-> finished; finite poses: %d of %d" % (int(np.isfinite(out[0]).all(axis=0).sum()), wl.T))
+        except (IndexError, ValueError, RuntimeError) as e:
+            print(what, "-> raised", type(e).__name__, str(e)[:80])
+        eng.close()
