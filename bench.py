@@ -1,31 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X-native ICM sweep: ICM pose-updates/s over full sweeps.
 
-    python bench.py                      # 1 GPU, workload S2 (100k poses / 10k landmarks / 720 beams)
+    python bench.py                                  # 1 GPU, workload S2 (100k poses / 10k landmarks / 720 beams)
+    python bench.py --gpus N --steps K --warmup W    # starts the N ranks itself (fresh child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # or is started as one of them
 
 A "step" is one full ICM sweep (reference `iterations_process_offline`, scripts/ICM_ROS.py:121-164:
 association of every kept beam, running-mean map, one Nelder-Mead solve per pose, map
 prune/merge) over the whole synthetic sequence, which is resident in HBM when timing starts.
 Poses are solved in the red-black order (the reference's sequential order is one dependent
-chain of T-1 solves and is used for parity, not throughput).  With N > 1 ONE sequence is sharded
-by contiguous pose blocks over the ranks, with one all-gather of the landmark sufficient
-statistics and two 48-byte halo exchanges per sweep.  Default `--scaling weak`: the sequence
-grows with the job (N x 100k poses through the same 10k-landmark field; every GPU owns a
-100k-pose block, i.e. the per-GPU work is the N = 1 workload).  `--scaling strong` shards the
-fixed 100k-pose sequence instead (BASELINE.json configs[4]); one sweep of it is under 1 ms on one
-GPU, so that mode is bounded by the serial Nelder-Mead chain and collective latency (DESIGN.md
-section 6).
+chain of T-1 solves and is used for parity, not throughput).
 
-Prints ONE JSON line on rank 0 (contract in the task description) with the two extra objects
-`roofline` (dominant kernel, measured with HIP events on the launch stream) and
-`cpu_baseline` (the NumPy oracle timed on one host core on a bounded prefix of the same
-workload).
+N > 1 (BASELINE.json configs[4]): the fixed S2 sequence is sharded by contiguous pose blocks
+over the ranks ("scaling": "strong"), one all-gather of the landmark sufficient statistics and
+one 48-byte halo all-gather per sweep.  The same job is then repeated on a sequence N times as
+long (every GPU owns a 100k-pose block: fixed work per GPU) and reported as the secondary
+record `"weak"` of the same JSON line.  `--scaling weak` swaps the two.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with the extra objects
+`roofline` (dominant kernel, HIP events on the launch stream), `cpu_baseline` (the C oracle on a
+bounded prefix of the same workload, host cores) and, at N = 1, `dropin` (the same sweep through the
+reference's call `ICM_ROS.iterations_process_offline`, host arrays in and out) and `config3`
+(S1 x 20 consecutive sweeps).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,7 +41,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 FP64 FMA lanes x 2 x 2.4 GHz (no MFMA on this path)
-FLOP_PER_ENERGY_EVAL = 180    # moment-form fun_xn: trig 24, observation quadratic form 67, priors 87
+MAX_SWEEPS_WITHOUT_REWIND = 40   # S2 leaves the association gate after ~50 consecutive sweeps
+RESET_EVERY = 12
 
 
 def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True):
@@ -85,7 +89,11 @@ def survey_bytes_per_pose(B, Kt, K, T):
     return 8 * B + 88 + 64 * Kt + 40.0 * K / T
 
 
-def cpu_baseline(wl, cfg, n_pose, schedule):
+# -------------------------------------------------------------------------------------------------
+# CPU baselines (the ONLY place bench.py touches oracle/): timed on the host cores, outside the
+# timed GPU region, rank 0 at N = 1 only
+# -------------------------------------------------------------------------------------------------
+def cpu_baseline_numpy(wl, cfg, n_pose, schedule):
     """The NumPy oracle (the reference's own arithmetic, library for library) on one core, on
     the first n_pose poses of the same workload at the full landmark count."""
     from oracle import icm_oracle as o
@@ -94,240 +102,392 @@ def cpu_baseline(wl, cfg, n_pose, schedule):
     u, odo = wl.u[:, :n_pose], wl.odometry[:, :n_pose]
     st = o.MapState(ocfg, wl.K)
     x = np.ascontiguousarray(wl.x_init[:, :n_pose]).copy()
-    t0 = time.perf_counter()
     kept = o.prefilter_all(scans, ocfg)
     t1 = time.perf_counter()
     try:
         o.sweep(ocfg, st, scans, u, odo, wl.x0, wl.map_init.copy(), x, schedule=schedule, kept=kept)
     except ValueError:
         pass  # a short prefix may leave no landmark above `cota`; the sweep work is done by then
-    t2 = time.perf_counter()
-    return (n_pose - 1) / (t2 - t1), t1 - t0
+    return (n_pose - 1) / (time.perf_counter() - t1)
 
 
-def cpu_baseline_c(wl, cfg, n_pose, schedule):
-    """The compiled C restatement of the same algorithm (oracle/icm_oracle_c.c, gcc -O2, one
-    core): brute-force association, per-beam energy, SciPy's Nelder-Mead -- what the reference's
-    sweep costs without the Python interpreter."""
+def cpu_baseline_c(wl, cfg, n_pose, schedule, threads):
+    """The compiled C restatement of the same algorithm (oracle/icm_oracle_c.c, gcc -O2):
+    literal (brute-force) cdist/argmin association, per-beam energy, SciPy's Nelder-Mead -- what
+    the reference's sweep costs without the Python interpreter.  threads = 1: the reference is
+    single-threaded."""
     from oracle import c_oracle as co
     scans = np.ascontiguousarray(wl.scans[:n_pose].T)
     u, odo = np.ascontiguousarray(wl.u[:, :n_pose]), np.ascontiguousarray(wl.odometry[:, :n_pose])
     kept = co.prefilter(cfg, scans)
     x = np.ascontiguousarray(wl.x_init[:, :n_pose]).copy()
+    co.set_threads(threads)
+    co.set_grid(False)
     t1 = time.perf_counter()
     try:
         co.sweep(cfg, kept, u, odo, wl.x0, wl.map_init, x, wl.K, schedule)
     except ValueError:
         pass
-    t2 = time.perf_counter()
-    return (n_pose - 1) / (t2 - t1)
+    dt = time.perf_counter() - t1
+    co.set_grid(True)
+    co.set_threads(0)
+    return (n_pose - 1) / dt
+
+
+# -------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` from a plain shell starts the ranks itself
+# -------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank job.  This process never touches the GPU (no torch.cuda call, no HIP
+    library loaded): it starts `python -m torch.distributed.run` as a CHILD process, which starts
+    one fresh rank process per GPU, relays rank 0's JSON line and exits with the job's code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0 or line is None:
+        raise SystemExit(rc if rc else 1)
+
+
+# -------------------------------------------------------------------------------------------------
+# one rank
+# -------------------------------------------------------------------------------------------------
+class Job:
+    """One workload resident on this rank's GPU and the step that sweeps it."""
+
+    def __init__(self, args, name, T, K, B, rank, world, local_rank, sharded, dist, factory=None):
+        from ICM_SLAM_tools import ConfigICM
+        from icmslam_hip.synthetic import make_workload
+        self.args, self.dist, self.world, self.rank, self.sharded = args, dist, world, rank, sharded
+        self.T, self.K, self.B = T, K, B
+        self.blk = (T + world - 1) // world
+        self.t_begin, self.t_end = min(rank * self.blk, T), min((rank + 1) * self.blk, T)
+        t0 = time.perf_counter()
+        self.wl = wl = make_workload(T, K, B, t_begin=self.t_begin, t_end=self.t_end)
+        self.t_gen = time.perf_counter() - t0
+        self.cfg = cfg = ConfigICM(D=dict(wl.config, schedule="redblack"))
+        t0 = time.perf_counter()
+        if factory is not None:     # test hook (tests/test_bench_launcher.py): an engine double with the phase API
+            self.eng = eng = factory(cfg, wl, rank, world, self.t_begin, self.t_end)
+        else:
+            from icmslam_hip import SweepEngine
+            self.eng = eng = SweepEngine(cfg, local_rank)
+            eng.upload(wl.scans, wl.odometry, wl.u, t_begin=self.t_begin, t_end=self.t_end, pose_major=True)
+        self.t_upload = time.perf_counter() - t0
+        if sharded:
+            from icmslam_hip.sharded import ShardedSweep
+            self.runner = ShardedSweep(eng, rank, world, T)
+            self.runner.set_state(wl.map_init, wl.x_init, wl.x0)
+            self.inner = lambda: self.runner.sweep("redblack")
+        else:
+            eng.set_state(wl.map_init, wl.x_init, wl.x0)
+            self.inner = lambda: eng.sweep_device("redblack")
+        self.nsweeps = 0
+        self.rewind = False
+
+    def enable_rewind(self):
+        """ICM on S2 is not a contraction: after ~50 consecutive sweeps poses
+        leave the 1 m association gate.  Runs longer than MAX_SWEEPS_WITHOUT_REWIND sweeps rewind
+        the state on the device every RESET_EVERY sweeps (inside the timed region, stated in
+        config.state_rewind); the default run does not."""
+        self.eng.snapshot_state()
+        self.rewind = True
+
+    def step(self):
+        if self.rewind and self.nsweeps and self.nsweeps % RESET_EVERY == 0:
+            self.eng.restore_state()
+        self.inner()
+        self.nsweeps += 1
+
+    def fence(self):
+        if self.args.device == "cuda":
+            import torch
+            torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.args.device == "cuda":
+                import torch
+                torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        """W untimed sweeps, then exactly K sweeps between two (barrier + device synchronise) fences;
+        the MAX over ranks of the elapsed time."""
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            import torch
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=self.args.device)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed
+
+    def close(self):
+        if hasattr(self.eng, "close"):
+            self.eng.close()
+
+
+def roofline(job, ms_per_step):
+    """Per-kernel launch times from HIP events on the launch stream (icm_enable_timing), over
+    three more sweeps; achieved = algorithmic bytes (or flops) per launch / average launch time."""
+    eng, args = job.eng, job.args
+    st = eng.last_stats()
+    eng.enable_timing(True)
+    nroof = 3
+    for _ in range(nroof):
+        job.inner()
+    job.fence()
+    kt = {k: v for k, v in eng.kernel_times().items() if v[1] > 0 and k != "k_prefilter"}
+    hier = eng.entry_path() == "hier"
+    eng.enable_timing(False)
+    # k_filtrar_* run on a side stream, concurrent with the solves: not on the critical path
+    side = tuple(k for k in kt if k.startswith("k_filtrar") or k == "k_neigh_table")
+    dom = max((k for k in kt if k not in side), key=lambda k: kt[k][0])
+
+    def ab_of(k, n_k):
+        return algorithmic_bytes(k, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof, hier)
+
+    per_kernel = {}
+    for k, (ms_k, n_k) in kt.items():
+        ab = ab_of(k, n_k)
+        per_kernel[k] = {"ms_per_launch": round(ms_k / n_k, 4), "launches_per_sweep": n_k / nroof,
+                         "GBps": round(ab / (ms_k / n_k * 1e-3) / 1e9, 1) if ab else None}
+
+    def hbm_roof(kname):
+        ms_k, n_k = kt[kname]
+        ab = ab_of(kname, n_k)
+        a_gbs = ab / (ms_k / n_k * 1e-3) / 1e9
+        # `traffic` is a PMC quantity (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile.sh):
+        # it cannot be collected from inside this process, so it is null here; the committed PMC
+        # summaries of this build are under profiles/ (r02_*_pmc_traffic_*.csv)
+        return {"bound": "hbm", "kernel": kname, "achieved": round(a_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(a_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(ms_k / n_k, 4), "launches_per_sweep": n_k / nroof,
+                "algorithmic_bytes_per_launch": int(ab)}
+
+    ms, n = kt[dom]
+    avg_ms, nl = ms / n, n / nroof
+    stream_kernel = max((k for k in kt if k not in side + ("k_solve",)), key=lambda k: kt[k][0])
+    if dom == "k_solve":
+        # the solves are not a bandwidth kernel: one lane per pose runs ~80 dependent energy
+        # evaluations from registers.  Their roofline is the FP64 vector rate; flops = (energy
+        # evaluations counted by the kernel itself) x (FP64 flops of one evaluation, counted from
+        # the kernel's ISA at build time: tools/count_eval_flops.py -> icm_flop_per_eval()).
+        eng.set_debug(True)
+        if hier:
+            eng.set_entry_path("hier")   # (debug alone would select the sort-based pipeline)
+        job.inner()
+        job.fence()
+        nfev = float(eng.solve_diag()[:, 2].sum())
+        eng.set_debug(False)
+        eng.set_entry_path("auto")
+        fpe = eng.flop_per_eval()
+        flops = nfev * fpe / nl
+        tfl = flops / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "valu_fp64", "kernel": dom, "achieved": round(tfl, 3), "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tfl / FP64_VALU_PEAK_TFLOPS, 5), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches_per_sweep": nl, "energy_evaluations_per_sweep": int(nfev),
+                "flop_per_evaluation": fpe, "flop_per_evaluation_source": "FP64 VALU instructions of one energy evaluation in the built kernel's ISA (fma = 2)",
+                "algorithmic_bytes_per_launch": int(ab_of(dom, n))}
+    else:
+        roof = hbm_roof(dom)
+    roof["hbm_stream_kernel"] = hbm_roof(stream_kernel)
+    roof["kernels_ms_per_sweep"] = {k: round(v[0] / nroof, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}
+    roof["kernels"] = per_kernel
+    roof["side_stream_kernels"] = list(side)
+    Kt = st["entries"] / max(eng.nloc, 1)
+    sweep_bytes = survey_bytes_per_pose(job.B, Kt, job.K, job.T) * (job.T - 1)
+    roof["sweep_algorithmic_GBps"] = round(sweep_bytes / (ms_per_step * 1e-3) / 1e9, 2)
+    roof["sweep_frac_of_hbm_peak"] = round(roof["sweep_algorithmic_GBps"] / (HBM_PEAK_GBS * job.world), 5)
+    return roof
+
+
+def dropin_record(job, steps, warmup):
+    """The reference's own call: mapa_refinado, x = ICM.iterations_process_offline(mapa_viejo, x)
+    (scripts/ICM_ROS.py:298-311 driver loop), host NumPy arrays in and out every sweep -- PCIe
+    included, so this is never `value`."""
+    import torch
+    from copy import deepcopy as copy
+    from ICM_ROS import ICM_ROS
+    wl = job.wl
+    icm = ICM_ROS(job.cfg)
+    icm.attach_engine(job.eng, wl.scans.T, wl.odometry, wl.u)   # the sequence is already in HBM
+    icm.x0 = wl.x0.reshape(3, 1)
+    icm.set_initial_state(wl.x_init, wl.map_init)
+    mapa_viejo, x = copy(icm.mapa_viejo), copy(icm.positions)
+    for _ in range(warmup):
+        mapa_refinado, x = icm.iterations_process_offline(mapa_viejo, x)
+        mapa_viejo = copy(mapa_refinado)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        mapa_refinado, x = icm.iterations_process_offline(mapa_viejo, x)
+        mapa_viejo = copy(mapa_refinado)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"call": "ICM_ROS.iterations_process_offline (host arrays in/out, PCIe inclusive)", "steps": steps,
+            "ms_per_step": round(1e3 * el / steps, 4), "value": round((job.T - 1) * steps / el, 1), "unit": "pose-updates/s"}
+
+
+def run_rank(args):
+    from icmslam_hip.synthetic import WORKLOADS
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    factory = None
+    if args.engine_factory:       # test hook: "module:function" building an engine double (CPU, gloo)
+        import importlib
+        mod, fn = args.engine_factory.split(":")
+        factory = getattr(importlib.import_module(mod), fn)
+    dist = None
+    sharded = world > 1 or args.force_sharded
+    if sharded:
+        import torch
+        import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:  # plain `python bench.py --force-sharded`
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+        if args.device == "cuda":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    ranks_seen = 1
+    if dist is not None:
+        import torch
+        one = torch.ones(1, dtype=torch.float64, device=args.device)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        assert ranks_seen == dist.get_world_size() == world
+
+    T1, K, B = WORKLOADS[args.workload]
+    modes = [args.scaling] if world == 1 else [args.scaling, "weak" if args.scaling == "strong" else "strong"]
+    records = {}
+    main_job = None
+    for mode in modes:
+        T = T1 * world if mode == "weak" else T1
+        job = Job(args, args.workload, T, K, B, rank, world, local_rank, sharded, dist, factory)
+        total = args.steps + args.warmup
+        if total > MAX_SWEEPS_WITHOUT_REWIND and not args.no_rewind and factory is None:
+            job.enable_rewind()
+        elapsed = job.timed(args.steps, args.warmup)
+        ms = 1e3 * elapsed / max(args.steps, 1)
+        rec = {"value": round((T - 1) * args.steps / elapsed, 1), "ms_per_step": round(ms, 4), "poses": T,
+               "poses_per_gpu": job.blk, "scaling": mode,
+               "workload": ("%s: synthetic %d poses / %d landmarks / %d beams, red-black ICM sweep" % (args.workload, T, K, B))
+               + ("" if world == 1 else
+                  (" -- ONE sequence of %d x %d poses, a %d-pose block per GPU" % (world, T1, job.blk) if mode == "weak"
+                   else " -- the %d-pose sequence split into %d-pose blocks (BASELINE.json configs[4])" % (T, job.blk)))}
+        records[mode] = rec
+        if mode == args.scaling:
+            main_job, main_ms = job, ms
+        else:
+            job.close()
+    job = main_job
+    rec = records[args.scaling]
+    st = job.eng.last_stats() if hasattr(job.eng, "last_stats") else {"kept_beams": None}
+    out = {
+        "metric": "ICM pose-updates/sec (full sweep)", "value": rec["value"], "unit": "pose-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": rec["workload"], "schedule": "redblack", "poses": rec["poses"], "poses_per_gpu": rec["poses_per_gpu"],
+                   "landmarks": K, "beams": B, "kept_beams": st["kept_beams"] if world == 1 else None,
+                   "parallelism": "pose-shard x%d" % world,
+                   "entry_pipeline": job.eng.entry_path() if hasattr(job.eng, "entry_path") else None,
+                   "state_rewind": ("initial state restored on the device every %d sweeps" % RESET_EVERY) if job.rewind
+                   else "none: %d consecutive sweeps from the initial state" % (args.steps + args.warmup),
+                   "collectives_per_sweep": 0 if not sharded else "1 all-gather of [3L+8] f64 statistics + 1 halo all-gather of 48 B per rank"},
+        "ranks_seen": ranks_seen,
+        "setup_s": {"generate": round(job.t_gen, 2), "upload_and_prefilter": round(job.t_upload, 2)},
+    }
+    for mode, r in records.items():
+        if mode != args.scaling:
+            out[mode] = r
+    if factory is None and not args.no_roofline:
+        out["roofline"] = roofline(job, main_ms)
+    if rank == 0 and world == 1 and factory is None and not args.no_extras:
+        out["dropin"] = dropin_record(job, max(args.steps // 2, 5), 2)
+    wl, cfg = job.wl, job.cfg
+    if rank == 0 and world == 1 and factory is None and args.cpu_poses != 0:
+        n_c = args.cpu_poses if args.cpu_poses > 0 else {"S2": 2500, "S1": 10000}.get(args.workload, job.T)
+        n_c = min(n_c, job.t_end)
+        v_c = cpu_baseline_c(wl, cfg, n_c, "redblack", 1)
+        out["cpu_baseline"] = {"value": round(v_c, 1), "unit": "pose-updates/s", "cores": 1, "kind": "port",
+                               "sample": "compiled C oracle (oracle/icm_oracle_c.c, gcc -O2, one thread; literal brute-force association "
+                                         "and per-beam energy like the reference), one red-black sweep over the first %d poses of "
+                                         "the same sequence at the full %d-landmark map; host has %d cores" % (n_c, K, os.cpu_count())}
+        n_py = min({"S2": 300, "S1": 1000}.get(args.workload, job.T), job.t_end)
+        v_py = cpu_baseline_numpy(wl, cfg, n_py, "redblack")
+        out["cpu_baseline_numpy"] = {"value": round(v_py, 2), "unit": "pose-updates/s", "cores": 1, "kind": "port",
+                                     "sample": "NumPy oracle (oracle/icm_oracle.py: the reference's arithmetic library for library, "
+                                               "interpreter included), first %d poses" % n_py}
+        out["gpu_over_cpu"] = {"vs_c_port": round(out["value"] / v_c, 1), "vs_numpy_port": round(out["value"] / v_py, 1)}
+    job.close()
+    if rank == 0 and world == 1 and factory is None and not args.no_extras and args.workload == "S2":
+        # BASELINE.json configs[2]: S1 (10k poses / 1k landmarks / 360 beams), 20 consecutive ICM iterations
+        j3 = Job(args, "S1", *WORKLOADS["S1"], rank, world, local_rank, False, None)
+        el = j3.timed(20, 2)
+        out["config3"] = {"workload": "S1: synthetic 10000 poses / 1000 landmarks / 360 beams, 20 consecutive red-black sweeps (BASELINE.json configs[2])",
+                          "steps": 20, "warmup": 2, "ms_per_step": round(1e3 * el / 20, 4), "value": round((j3.T - 1) * 20 / el, 1),
+                          "unit": "pose-updates/s"}
+        j3.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="S2", help="S2 (BASELINE metric config), S1, tiny")
     ap.add_argument("--cpu-poses", type=int, default=-1, help="prefix length of the CPU baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak = the sequence has N x the workload's poses (fixed work per GPU); "
-                         "strong = the workload's sequence split N ways")
+    ap.add_argument("--no-extras", action="store_true", help="skip the drop-in and config-3 records")
+    ap.add_argument("--no-rewind", action="store_true", help="never rewind the state, however many sweeps")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="N > 1: strong = the workload's sequence split N ways (BASELINE configs[4], the headline); "
+                         "weak = the sequence has N x the workload's poses (fixed work per GPU); the other one is "
+                         "reported as a secondary record")
     ap.add_argument("--force-sharded", action="store_true",
                     help="drive even a 1-rank run through the sharded path (torch.distributed + RCCL all-gathers)")
+    ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda", help="cpu: launcher tests only (with --engine-factory)")
+    ap.add_argument("--engine-factory", default="", help="test hook: module:function returning an engine double")
     args = ap.parse_args()
-
-    import torch
-    from ICM_SLAM_tools import ConfigICM
-    from icmslam_hip import SweepEngine
-    from icmslam_hip.synthetic import WORKLOADS, make_workload
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    dist = None
-    sharded = world > 1 or args.force_sharded
-    if sharded:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if "MASTER_ADDR" not in os.environ:  # plain `python bench.py --force-sharded`
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    T1, K, B = WORKLOADS[args.workload]
-    T = T1 * world if args.scaling == "weak" else T1   # poses of the whole (sharded) sequence
-    blk = (T + world - 1) // world
-    t_begin, t_end = min(rank * blk, T), min((rank + 1) * blk, T)
-    t0 = time.perf_counter()
-    wl = make_workload(T, K, B, t_begin=t_begin, t_end=t_end)
-    t_gen = time.perf_counter() - t0
-    cfg = ConfigICM(D=wl.config)
-    schedule = "redblack"
-
-    eng = SweepEngine(cfg, local_rank)
-    t0 = time.perf_counter()
-    eng.upload(wl.scans, wl.odometry, wl.u, t_begin=t_begin, t_end=t_end, pose_major=True)
-    t_upload = time.perf_counter() - t0
-    if sharded:
-        from icmslam_hip.sharded import ShardedSweep
-        runner = ShardedSweep(eng, rank, world, T)
-        runner.set_state(wl.map_init, wl.x_init, wl.x0)
-        step = lambda: runner.sweep(schedule)  # noqa: E731
-    else:
-        eng.set_state(wl.map_init, wl.x_init, wl.x0)
-        step = lambda: eng.sweep_device(schedule)  # noqa: E731
-
-    # ICM on this synthetic sequence is not a contraction: the noisy odometry prior walks the poses
-    # away from the 1 m association gate, after ~50 sweeps landmarks are re-created en masse and at
-    # sweep 72 the map capacity L overflows (IndexError, as in the reference; identical in both
-    # entry pipelines).  So that ANY --steps measures the same work per step, the state is rewound
-    # to the initial one every RESET_EVERY sweeps by a device-side copy (icm_restore_state, ~20 MB
-    # device-to-device, stream-ordered, ~10 us) -- inside the timed region, on every rank.
-    RESET_EVERY = 12
-    eng.snapshot_state()
-    inner_step, nsweeps = step, [0]
-
-    def step():  # noqa: F811
-        if nsweeps[0] and nsweeps[0] % RESET_EVERY == 0:
-            eng.restore_state()
-        inner_step()
-        nsweeps[0] += 1
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
-    value = (T - 1) * args.steps / elapsed
-
-    # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream
-    roof = None
-    st = eng.last_stats()
-    if not args.no_roofline:
-        eng.enable_timing(True)
-        nroof = 3
-        for _ in range(nroof):
-            inner_step()   # (no rewind here: at most 4 sweeps past the last one, well inside the stable range)
-        fence()
-        kt = {k: v for k, v in eng.kernel_times().items() if v[1] > 0 and k != "k_prefilter"}
-        hier = eng.entry_path() == "hier"
-        eng.enable_timing(False)
-        # k_filtrar_grid is one workgroup on a side stream, concurrent with the solves: not on
-        # the critical path and not a bandwidth kernel, so it is never the roofline subject
-        side = ("k_filtrar_grid", "k_neigh_table")   # side stream, under the solves
-        dom = max((k for k in kt if k not in side), key=lambda k: kt[k][0])
-        per_kernel = {}
-        for k, (ms_k, n_k) in kt.items():
-            ab = algorithmic_bytes(k, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof, hier)
-            per_kernel[k] = {"ms_per_launch": round(ms_k / n_k, 4), "launches_per_sweep": n_k / nroof,
-                             "GBps": round(ab / (ms_k / n_k * 1e-3) / 1e9, 1) if ab else None}
-        ms, n = kt[dom]
-        avg_ms = ms / n
-        nl = n / nroof
-        abytes = algorithmic_bytes(dom, st["kept_beams"], st["entries"], eng.nloc, eng.L, nl, hier)
-        ach = abytes / (avg_ms * 1e-3) / 1e9
-        def hbm_roof(kname):
-            ms_k, n_k = kt[kname]
-            ab = algorithmic_bytes(kname, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof, hier)
-            a_gbs = ab / (ms_k / n_k * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": kname, "achieved": round(a_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a_gbs / HBM_PEAK_GBS, 5), "traffic": traffic_of(kname),
-                    "avg_launch_ms": round(ms_k / n_k, 4), "launches_per_sweep": n_k / nroof,
-                    "algorithmic_bytes_per_launch": int(ab)}
-
-        def traffic_of(kname):
-            tf = os.path.join(ROOT, "profiles", "traffic.json")
-            try:
-                return json.load(open(tf)).get(args.workload, {}).get(kname)
-            except Exception:
-                return None
-
-        stream_kernel = max((k for k in kt if k not in side + ("k_solve",)), key=lambda k: kt[k][0])
-        if dom == "k_solve":
-            # the solves are not a bandwidth kernel: one lane per pose runs ~85 dependent energy
-            # evaluations from registers.  Their roofline is the FP64 vector rate; the flops are the
-            # measured number of energy evaluations x the flops of one evaluation.
-            eng.set_debug(True)
-            if hier:
-                eng.set_entry_path("hier")   # (debug alone would select the sort-based pipeline)
-            inner_step()   # (no rewind here: at most 4 sweeps past the last one, well inside the stable range)
-            fence()
-            nfev = float(eng.solve_diag()[:, 2].sum())
-            eng.set_debug(False)
-            eng.set_entry_path("auto")
-            flops = nfev * FLOP_PER_ENERGY_EVAL / nl
-            tfl = flops / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "valu_fp64", "kernel": dom, "achieved": round(tfl, 3), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tfl / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic_of(dom), "avg_launch_ms": round(avg_ms, 4),
-                    "launches_per_sweep": nl, "energy_evaluations_per_sweep": int(nfev),
-                    "flop_per_evaluation": FLOP_PER_ENERGY_EVAL, "algorithmic_bytes_per_launch": int(abytes)}
-        else:
-            roof = hbm_roof(dom)
-        roof["hbm_stream_kernel"] = hbm_roof(stream_kernel)
-        roof["kernels_ms_per_sweep"] = {k: round(v[0] / nroof, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}
-        roof["kernels"] = per_kernel
-        roof["note"] = ("k_solve: FP64-VALU/latency bound (one lane per pose, a launch lasts as long as its slowest pose's chain "
-                        "of Nelder-Mead evaluations); k_assoc_group: the HBM-streaming kernel; k_filtrar_grid: one workgroup on "
-                        "a side stream under the solves")
-        Kt = st["entries"] / max(eng.nloc, 1)
-        sweep_bytes = survey_bytes_per_pose(B, Kt, K, T) * (T - 1)
-        roof["sweep_algorithmic_GBps"] = round(sweep_bytes / (ms_per_step * 1e-3) / 1e9, 2)
-        roof["sweep_frac_of_hbm_peak"] = round(roof["sweep_algorithmic_GBps"] / (HBM_PEAK_GBS * world), 5)
-
-    out = {
-        "metric": "ICM pose-updates/sec (full sweep)", "value": round(value, 1), "unit": "pose-updates/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": ("%s: synthetic %d poses / %d landmarks / %d beams, red-black ICM sweep" % (args.workload, T, K, B))
-                               + ("" if world == 1 else
-                                  (" -- ONE sequence of %d x %d poses, a %d-pose block per GPU" % (world, T1, blk) if args.scaling == "weak"
-                                   else " -- the %d-pose sequence split into %d-pose blocks" % (T, blk))),
-                   "schedule": schedule, "poses": T, "poses_per_gpu": blk, "landmarks": K, "beams": B,
-                   "kept_beams": st["kept_beams"] if world == 1 else None,
-                   "parallelism": "pose-shard x%d" % world, "entry_pipeline": eng.entry_path(),
-                   "state_rewind": "initial state restored on the device every %d sweeps" % RESET_EVERY,
-                   "collectives_per_sweep": 0 if not sharded else "1 all-gather of [3L+8] f64 statistics + 2 halo all-gathers of 48 B per rank"},
-        "setup_s": {"generate": round(t_gen, 2), "upload_and_prefilter": round(t_upload, 2)},
-    }
-    if roof is not None:
-        out["roofline"] = roof
-    if rank == 0 and world == 1 and args.cpu_poses != 0:
-        n_c = args.cpu_poses if args.cpu_poses > 0 else {"S2": 2500, "S1": 10000}.get(args.workload, T)
-        n_c = min(n_c, t_end)
-        v_c = cpu_baseline_c(wl, cfg, n_c, schedule)
-        out["cpu_baseline"] = {"value": round(v_c, 1), "unit": "pose-updates/s", "cores": 1, "kind": "port",
-                               "sample": "compiled C oracle (oracle/icm_oracle_c.c, gcc -O2, one core; brute-force association "
-                                         "and per-beam energy like the reference), one red-black sweep over the first %d poses of "
-                                         "the same sequence at the full %d-landmark map; host has %d cores" % (n_c, K, os.cpu_count())}
-        n_py = min({"S2": 300, "S1": 1000}.get(args.workload, T), t_end)
-        v_py, _ = cpu_baseline(wl, cfg, n_py, schedule)
-        out["cpu_baseline_numpy"] = {"value": round(v_py, 2), "unit": "pose-updates/s", "cores": 1, "kind": "port",
-                                     "sample": "NumPy oracle (oracle/icm_oracle.py: the reference's arithmetic library for library, "
-                                               "interpreter included), first %d poses" % n_py}
-        out["gpu_over_cpu"] = {"vs_c_port": round(value / v_c, 1), "vs_numpy_port": round(value / v_py, 1)}
-    if rank == 0:
-        print(json.dumps(out))
-    eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if args.device == "cpu" and not args.engine_factory:
+        raise SystemExit("bench.py: there is no CPU path; --device cpu is for the launcher test with an engine double")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])
+        return
+    run_rank(args)
 
 
 if __name__ == "__main__":

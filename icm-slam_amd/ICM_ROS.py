@@ -128,16 +128,40 @@ class ICM_ROS(ROS):
     # ------------------------------------------------------------------------------------
     # the hot path
     # ------------------------------------------------------------------------------------
+    def _sequence_key(self):
+        """Identity of the uploaded sequence: shapes, buffer addresses and cheap checksums of all
+        three arrays.  The reference reads `mediciones`, `odometria` and `u` afresh on every call
+        (scripts/ICM_ROS.py:127-158); replacing any of them -- also by a same-shaped array that lands
+        at a recycled address -- must reach the device copy."""
+        m, o, u = self.mediciones, self.odometria, self.u
+
+        def chk(a, cols):   # strided column sample (first and last column always in): microseconds per call
+            if a.ndim != 2 or not a.size:
+                return 0.0
+            step = max(1, a.shape[1] // cols)
+            return float(a[:, ::step].sum()) + float(a[:, -1].sum())
+
+        return (m.shape, o.shape, u.shape,
+                m.__array_interface__["data"][0], o.__array_interface__["data"][0], u.__array_interface__["data"][0],
+                chk(m, 64), chk(o, 2048), chk(u, 2048))
+
     def _get_engine(self):
-        m = self.mediciones
-        key = (m.shape, m.__array_interface__["data"][0], self.odometria.__array_interface__["data"][0],
-               float(m[:, :: max(1, m.shape[1] // 64)].sum()) if m.size else 0.0)
+        key = self._sequence_key()
         if self._engine is None:
             self._engine = SweepEngine(self.config, self.device)
         if key != self._seq_key:
             self._engine.upload(self.mediciones, self.odometria, self.u)
             self._seq_key = key
         return self._engine
+
+    def attach_engine(self, engine, mediciones, odometria, u):
+        """Adopt a SweepEngine that already holds this sequence in HBM (uploaded and pre-filtered
+        by the caller) instead of uploading it again."""
+        self.mediciones, self.odometria, self.u = mediciones, odometria, u
+        if (engine.B, engine.T) != tuple(np.shape(mediciones)) or engine.nloc != engine.T:
+            raise ValueError("attach_engine: the engine holds a different sequence")
+        self._engine = engine
+        self._seq_key = self._sequence_key()
 
     def invalidate_sequence(self):
         """Force a re-upload (and a new scan pre-filter) on the next sweep, e.g. after

@@ -17,6 +17,7 @@
 
 #include "../../include/icmslam.h"
 #include "icm_host.hpp"
+#include "eval_flops.h"
 #include "icm_kernels.hip"
 
 using namespace icm;
@@ -185,7 +186,10 @@ static inline int nblocks_threads(int64_t n) { return (int)((n + kBlock - 1) / k
 
 extern "C" {
 
-const char* icm_version(void) { return "icmslam-hip 0.1 (gfx950)"; }
+const char* icm_version(void) { return "icmslam-hip 0.2 (gfx950)"; }
+
+int icm_flop_per_eval(void) { return ICM_FLOP_PER_EVAL; }
+int icm_valu_per_eval(void) { return ICM_VALU_PER_EVAL; }
 
 const char* icm_last_error(const icm_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 

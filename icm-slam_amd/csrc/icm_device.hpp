@@ -14,11 +14,18 @@ constexpr double kTwoPi = 6.283185307179586;
 constexpr double kHalfPi = 1.5707963267948966;
 constexpr int kWave = 64;
 
+// 1 only in eval_probe.hip (tools/count_eval_flops.py): the rarely taken slow paths (fmod in
+// wrap_pi, generic sincos beyond |d| = 0.25) are compiled out so that the probe's ISA is the
+// straight-line path an energy evaluation executes.
+#ifndef ICM_PROBE_FAST_TRIG_ONLY
+#define ICM_PROBE_FAST_TRIG_ONLY 0
+#endif
+
 // entrepi (reference scripts/ICM_SLAM_tools.py:455-463): numpy mod (sign of the divisor),
 // then fold (pi, 2pi) down.  Result in [-pi, pi].
 __device__ __forceinline__ double wrap_pi(double a) {
     // fmod(a, b) == a exactly whenever |a| < b: the usual case, without fmod's division loop
-    double r = fabs(a) < kTwoPi ? a : fmod(a, kTwoPi);
+    double r = (ICM_PROBE_FAST_TRIG_ONLY || fabs(a) < kTwoPi) ? a : fmod(a, kTwoPi);
     if (r < 0.0) r += kTwoPi;
     if (r > kPi) r -= kTwoPi;
     return r;
@@ -209,7 +216,7 @@ __device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const P
                                                       double th) {
     const double dl = th - m.tho;
     double cth, sth, al, be;
-    if (fabs(dl) <= 0.25) {
+    if (ICM_PROBE_FAST_TRIG_ONLY || fabs(dl) <= 0.25) {
         small_sincosm1(dl, be, al);
         cth = m.co + (m.co * al - m.so * be);
         sth = m.so + (m.so * al + m.co * be);

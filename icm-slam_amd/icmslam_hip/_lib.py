@@ -77,6 +77,8 @@ SIGNATURES = {
     "icm_get_entry_path": (C.c_int, [_H]),
     "icm_set_energy_form": (C.c_int, [_H, C.c_int]),
     "icm_version": (C.c_char_p, []),
+    "icm_flop_per_eval": (C.c_int, []),
+    "icm_valu_per_eval": (C.c_int, []),
 }
 
 _lib = None

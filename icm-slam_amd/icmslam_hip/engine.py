@@ -384,6 +384,10 @@ class SweepEngine:
             out[name.value.decode()] = (ms.value, n.value)
         return out
 
+    def flop_per_eval(self):
+        """FP64 flops of one energy evaluation (fma = 2), counted from the built kernel's ISA."""
+        return int(self.lib.icm_flop_per_eval())
+
     def last_stats(self):
         a = np.zeros(4, dtype=np.int64)
         self._chk(self.lib.icm_last_stats(self.h, lptr(a)))

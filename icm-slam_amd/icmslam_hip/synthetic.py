@@ -207,4 +207,5 @@ WORKLOADS = {
     "S1": (10_000, 1_000, 360),
     "S2": (100_000, 10_000, 720),
     "tiny": (600, 64, 180),
+    "mini": (700, 64, 180),      # like tiny, and twice its length (the 2-rank weak-scaling job) also ends on a scan with beams
 }

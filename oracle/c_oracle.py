@@ -27,6 +27,7 @@ def load():
             subprocess.check_call(["make", "-C", _HERE])
         _lib = C.CDLL(_PATH)
         _lib.oc_filtrar_z.restype = C.c_int64
+        _lib.oc_get_threads.restype = C.c_int
     return _lib
 
 
@@ -74,9 +75,25 @@ def prefilter(cfg, scans_BT):
     return off, k, np.concatenate(ds), ang[k], np.concatenate(bxs), np.concatenate(bys)
 
 
-def sweep(cfg, kept, u, odo, x0, mapa_viejo, x, lact=None, schedule="sequential"):
+def set_threads(n):
+    """OpenMP threads of the sweep (0 = all cores).  Results do not depend on it."""
+    load().oc_set_threads(C.c_int(int(n)))
+
+
+def get_threads():
+    return int(load().oc_get_threads())
+
+
+def set_grid(on):
+    """True (default): associate through a uniform grid (exactly the brute-force answer);
+    False: the literal scan over every landmark."""
+    load().oc_set_grid(C.c_int(int(bool(on))))
+
+
+def sweep(cfg, kept, u, odo, x0, mapa_viejo, x, lact=None, schedule="sequential", assoc=None):
     """One sweep on prefiltered beams `kept` (from prefilter()).  x (3,T) is updated in place.
-    Returns (map (2,K'), counts (L), K', raw (y, counts, lact)) or None if scan 0 is empty."""
+    Returns (map (2,K'), counts (L), K', raw (y, counts, lact)) or None if scan 0 is empty.
+    assoc: optional dict filled with 'labels' (nnz) and 'targets' (2,nnz) = y[:, c] per kept beam."""
     lib = load()
     c = _cfg(cfg)
     off, k, d, ang, bx, by = kept
@@ -91,9 +108,16 @@ def sweep(cfg, kept, u, odo, x0, mapa_viejo, x, lact=None, schedule="sequential"
     Ko, la = C.c_int64(0), C.c_int64(0)
     d, ang, bx, by = _f(d), _f(ang), _f(bx), _f(by)
     odo, u, x0 = _f(odo), _f(u), _f(np.asarray(x0, dtype=np.float64).reshape(3))
-    rc = lib.oc_sweep(C.byref(c), C.c_int64(T), off.ctypes.data_as(_lp), _p(d), _p(ang), _p(bx), _p(by), _p(odo), _p(u),
-                      _p(x0), _p(mv), C.c_int64(K), C.c_int64(lact), C.c_int({"sequential": 0, "redblack": 1}[schedule]),
-                      _p(x), _p(mo), _p(co), C.byref(Ko), _p(yr), _p(cr), C.byref(la))
+    nnz = int(off[-1])
+    lab = np.zeros(max(nnz, 1), dtype=np.int64) if assoc is not None else None
+    tg = np.zeros((2, max(nnz, 1))) if assoc is not None else None
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    rc = lib.oc_sweep2(C.byref(c), C.c_int64(T), off.ctypes.data_as(_lp), _p(d), _p(ang), _p(bx), _p(by), _p(odo), _p(u),
+                       _p(x0), _p(mv), C.c_int64(K), C.c_int64(lact), C.c_int({"sequential": 0, "redblack": 1}[schedule]),
+                       _p(x), _p(mo), _p(co), C.byref(Ko), _p(yr), _p(cr), C.byref(la),
+                       lab.ctypes.data_as(_lp) if lab is not None else None, _p(tg) if tg is not None else None)
+    if assoc is not None:
+        assoc["labels"], assoc["targets"] = lab[:nnz], tg[:, :nnz]
     if rc == 1:
         return None
     if rc == -3:

@@ -17,6 +17,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define PI 3.141592653589793
 #define TWO_PI 6.283185307179586
@@ -223,6 +226,7 @@ int oc_filtrar(const oc_config* cfg, const double* y, const double* cnt, int64_t
         if (cnt[i] >= cfg->cota) { px[n] = y[i]; py[n] = y[L + i]; pc[n] = cnt[i]; ++n; }
     if (n == 0) { free(px); return -4; }
     double amax = 0.0;
+#pragma omp parallel for reduction(max : amax) if (n > 512)
     for (int64_t i = 0; i < n; ++i)
         for (int64_t j = 0; j < n; ++j) {
             double dx = px[i] - px[j], dy = py[i] - py[j], d = sqrt(dx * dx + dy * dy);
@@ -231,6 +235,7 @@ int oc_filtrar(const oc_config* cfg, const double* y, const double* cnt, int64_t
     int64_t* c = (int64_t*)malloc(sizeof(int64_t) * (size_t)n * 3);
     int64_t *nn = c + n, *rank = c + 2 * n;
     double* nd = (double*)malloc(sizeof(double) * (size_t)n);
+#pragma omp parallel for if (n > 512)
     for (int64_t i = 0; i < n; ++i) {
         double best = INFINITY; int64_t bj = 0;
         for (int64_t j = 0; j < n; ++j) {
@@ -263,13 +268,100 @@ int oc_filtrar(const oc_config* cfg, const double* y, const double* cnt, int64_t
     return 0;
 }
 
+/* ---- association of one world point, scripts/ICM_SLAM_tools.py:169-172 ----
+ * cdist + argmin (first index on ties) + gate d > dist_thr -> -1.  Brute force over the km
+ * matchable columns, or -- same answer, O(1) instead of O(km) -- through a uniform grid with
+ * cell edge >= dist_thr: the winner of the brute-force argmin either lies within dist_thr of
+ * the point (then it is in the 3x3 cells around it, and so is every landmark that ties with it)
+ * or it is gated to -1 whatever it was.  oc_set_grid(0) forces the literal scan;
+ * tests/test_oracle_golden.py checks the two against each other. */
+typedef struct {
+    double x0, y0, inv;
+    int64_t nx, ny;
+    int64_t* start; /* [nx*ny+1] */
+    int64_t* idx;   /* landmark ids, cell-sorted, ascending inside a cell */
+} oc_grid;
+
+static int g_use_grid = 1;
+static int g_threads = 0; /* 0 = OpenMP default */
+void oc_set_grid(int on) { g_use_grid = on; }
+void oc_set_threads(int n) { g_threads = n; }
+int oc_get_threads(void) {
+#ifdef _OPENMP
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static int64_t cell_of(double v, double v0, double inv, int64_t n) {
+    double c = floor((v - v0) * inv);
+    if (!(c > 0.0)) return 0;
+    if (c > (double)(n - 1)) return n - 1;
+    return (int64_t)c;
+}
+
+static int grid_build(oc_grid* g, const double* mx, const double* my, int64_t km, double cell) {
+    g->start = 0; g->idx = 0;
+    if (km <= 0) return 0;
+    double x0 = mx[0], x1 = mx[0], y0 = my[0], y1 = my[0];
+    for (int64_t i = 1; i < km; ++i) {
+        if (mx[i] < x0) x0 = mx[i];
+        if (mx[i] > x1) x1 = mx[i];
+        if (my[i] < y0) y0 = my[i];
+        if (my[i] > y1) y1 = my[i];
+    }
+    if (!(x1 - x0 < 1e300) || !(y1 - y0 < 1e300) || !(cell > 0.0)) return 0; /* non-finite map: literal scan */
+    while (((x1 - x0) / cell + 1.0) * ((y1 - y0) / cell + 1.0) > 16.0 * (double)km + 4096.0) cell *= 2.0;
+    g->x0 = x0; g->y0 = y0; g->inv = 1.0 / cell;
+    g->nx = (int64_t)floor((x1 - x0) / cell) + 1; g->ny = (int64_t)floor((y1 - y0) / cell) + 1;
+    int64_t nc = g->nx * g->ny;
+    g->start = (int64_t*)calloc((size_t)nc + 1, sizeof(int64_t));
+    g->idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)km);
+    int64_t* fill = (int64_t*)calloc((size_t)nc + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < km; ++i) g->start[cell_of(my[i], y0, g->inv, g->ny) * g->nx + cell_of(mx[i], x0, g->inv, g->nx) + 1]++;
+    for (int64_t c = 0; c < nc; ++c) g->start[c + 1] += g->start[c];
+    for (int64_t i = 0; i < km; ++i) { /* ascending i inside every cell */
+        int64_t c = cell_of(my[i], y0, g->inv, g->ny) * g->nx + cell_of(mx[i], x0, g->inv, g->nx);
+        g->idx[g->start[c] + fill[c]++] = i;
+    }
+    free(fill);
+    return 1;
+}
+
+static int64_t associate_point(const oc_grid* g, const double* mx, const double* my, int64_t km, double wx, double wy, double thr) {
+    double best = INFINITY; int64_t bid = -1;
+    if (g && g->start) {
+        int64_t cx = cell_of(wx, g->x0, g->inv, g->nx), cy = cell_of(wy, g->y0, g->inv, g->ny);
+        for (int64_t ry = cy > 0 ? cy - 1 : 0; ry <= (cy + 1 < g->ny ? cy + 1 : g->ny - 1); ++ry)
+            for (int64_t rx = cx > 0 ? cx - 1 : 0; rx <= (cx + 1 < g->nx ? cx + 1 : g->nx - 1); ++rx)
+                for (int64_t p = g->start[ry * g->nx + rx]; p < g->start[ry * g->nx + rx + 1]; ++p) {
+                    int64_t i = g->idx[p];
+                    double dx = mx[i] - wx, dy = my[i] - wy, d = sqrt(dx * dx + dy * dy);
+                    if (d < best || (d == best && i < bid)) { best = d; bid = i; }
+                }
+    } else {
+        for (int64_t i = 0; i < km; ++i) {
+            double dx = mx[i] - wx, dy = my[i] - wy, d = sqrt(dx * dx + dy * dy);
+            if (d < best) { best = d; bid = i; }
+        }
+    }
+    return (bid >= 0 && !(best > thr)) ? bid : -1;
+}
+
 /* ---- one sweep, scripts/ICM_ROS.py:121-164 in the three-phase form ----
  * Kept beams as CSR by pose (off[T+1]; d, ang, bx, by).  schedule 0 = reference order,
- * 1 = red-black.  x (3,T) in place.  Returns 0, -3 (IndexError cases), -4 (empty map), 1 (scan 0 empty). */
-int oc_sweep(const oc_config* cfg, int64_t T, const int64_t* off, const double* bd, const double* bang,
-             const double* bx, const double* by, const double* odo, const double* u, const double* x0,
-             const double* map_in, int64_t K, int64_t lact_in, int schedule, double* x, double* map_out,
-             double* cnt_out, int64_t* K_out, double* y_raw_out, double* cnt_raw_out, int64_t* lact_raw_out) {
+ * 1 = red-black.  x (3,T) in place.  Returns 0, -3 (IndexError cases), -4 (empty map), 1 (scan 0 empty).
+ * labels_out / tgt_out (optional, nnz / 2*nnz): label of every kept beam and its target y[:, c].
+ * OpenMP (when built with -fopenmp) spreads the per-pose association and the solves of one
+ * colour over threads; every pose is still computed by one thread with the same arithmetic, and
+ * the running means are folded in pose order by one thread, so results do not depend on the
+ * thread count. */
+int oc_sweep2(const oc_config* cfg, int64_t T, const int64_t* off, const double* bd, const double* bang,
+              const double* bx, const double* by, const double* odo, const double* u, const double* x0,
+              const double* map_in, int64_t K, int64_t lact_in, int schedule, double* x, double* map_out,
+              double* cnt_out, int64_t* K_out, double* y_raw_out, double* cnt_raw_out, int64_t* lact_raw_out,
+              int64_t* labels_out, double* tgt_out) {
     const int64_t L = cfg->L, nnz = off[T];
     if (off[1] == off[0]) return 1;
     if (off[T] == off[T - 1]) return -3;
@@ -280,25 +372,33 @@ int oc_sweep(const oc_config* cfg, int64_t T, const int64_t* off, const double* 
     int64_t* lab = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nnz + 1));
     int64_t lact = lact_in, km = K < lact_in ? K : lact_in;
     int rc = 0;
-    /* phases A + B in pose order: project with the previous-sweep pose, associate against the
-     * fixed mapa_viejo, fold into the running means, record y[:, c] */
-    for (int64_t t = 0; t < T && rc == 0; ++t) {
+    oc_grid grid; grid.start = 0; grid.idx = 0;
+    const int have_grid = g_use_grid && km > 64 && grid_build(&grid, map_in, map_in + K, km, cfg->dist_thr > 0.0 ? cfg->dist_thr : 1.0);
+#ifdef _OPENMP
+    const int nthr = g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    const int nthr = 1;
+#endif
+    (void)nthr;
+    /* phase A: project with the previous-sweep pose, associate against the fixed mapa_viejo */
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthr)
+    for (int64_t t = 0; t < T; ++t) {
         int64_t j0 = off[t], n = off[t + 1] - j0;
         if (n == 0) continue;
         const double px = t == 0 ? x0[0] : x[t], py = t == 0 ? x0[1] : x[T + t], th = t == 0 ? x0[2] : x[2 * T + t];
         double ct = cos(th - HALF_PI), st = sin(th - HALF_PI);
-        int anynew = 0;
         for (int64_t j = j0; j < j0 + n; ++j) {
             double wx = (bx[j] * ct + by[j] * (-st)) + px, wy = (bx[j] * st + by[j] * ct) + py;
-            double best = INFINITY; int64_t bid = -1;
-            for (int64_t i = 0; i < km; ++i) {
-                double dx = map_in[i] - wx, dy = map_in[K + i] - wy, d = sqrt(dx * dx + dy * dy);
-                if (d < best) { best = d; bid = i; }
-            }
-            lab[j] = (bid >= 0 && !(best > cfg->dist_thr)) ? bid : -1;
-            if (lab[j] < 0) anynew = 1;
+            lab[j] = associate_point(have_grid ? &grid : 0, map_in, map_in + K, km, wx, wy, cfg->dist_thr);
             tx[j] = wx; ty[j] = wy; /* world point for now */
         }
+    }
+    /* phase B in pose order: new-landmark ids, running means, record y[:, c] */
+    for (int64_t t = 0; t < T && rc == 0; ++t) {
+        int64_t j0 = off[t], n = off[t + 1] - j0;
+        if (n == 0) continue;
+        int anynew = 0;
+        for (int64_t j = j0; j < j0 + n; ++j) if (lab[j] < 0) anynew = 1;
         if (anynew) {
             if (lact >= L) { rc = -3; break; }
             for (int64_t j = j0; j < j0 + n; ++j) if (lab[j] < 0) lab[j] = lact;
@@ -318,10 +418,13 @@ int oc_sweep(const oc_config* cfg, int64_t T, const int64_t* off, const double* 
         }
         for (int64_t j = j0; j < j0 + n; ++j) { tx[j] = y[lab[j]]; ty[j] = y[L + lab[j]]; }
     }
+    if (rc == 0 && labels_out) memcpy(labels_out, lab, sizeof(int64_t) * (size_t)nnz);
+    if (rc == 0 && tgt_out) { memcpy(tgt_out, tx, sizeof(double) * (size_t)nnz); memcpy(tgt_out + nnz, ty, sizeof(double) * (size_t)nnz); }
     /* phase C */
     if (rc == 0) {
         int passes = schedule == 0 ? 1 : 2;
-        for (int pass = 0; pass < passes; ++pass)
+        for (int pass = 0; pass < passes; ++pass) {
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthr) if (schedule == 1)
             for (int64_t t = 1; t < T; ++t) {
                 if (schedule == 1 && (t & 1) != (pass == 0 ? 1 : 0)) continue;
                 int64_t j0 = off[t], n = off[t + 1] - j0;
@@ -344,11 +447,21 @@ int oc_sweep(const oc_config* cfg, int64_t T, const int64_t* off, const double* 
                 nelder_mead(&p, st, res, 0, 0);
                 x[t] = res[0]; x[T + t] = res[1]; x[2 * T + t] = res[2];
             }
+        }
         if (y_raw_out) memcpy(y_raw_out, y, sizeof(double) * (size_t)(2 * L));
         if (cnt_raw_out) memcpy(cnt_raw_out, cnt, sizeof(double) * (size_t)L);
         if (lact_raw_out) *lact_raw_out = lact;
         rc = oc_filtrar(cfg, y, cnt, lact, map_out, cnt_out, K_out);
     }
+    free(grid.start); free(grid.idx);
     free(lab); free(tx); free(y);
     return rc;
+}
+
+int oc_sweep(const oc_config* cfg, int64_t T, const int64_t* off, const double* bd, const double* bang,
+             const double* bx, const double* by, const double* odo, const double* u, const double* x0,
+             const double* map_in, int64_t K, int64_t lact_in, int schedule, double* x, double* map_out,
+             double* cnt_out, int64_t* K_out, double* y_raw_out, double* cnt_raw_out, int64_t* lact_raw_out) {
+    return oc_sweep2(cfg, T, off, bd, bang, bx, by, odo, u, x0, map_in, K, lact_in, schedule, x, map_out, cnt_out, K_out,
+                     y_raw_out, cnt_raw_out, lact_raw_out, 0, 0);
 }

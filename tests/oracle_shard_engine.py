@@ -102,7 +102,9 @@ class OracleShardEngine:
     def sweep_finish(self):
         st = o.MapState(self.cfg, self.lact_raw)
         st.cant_obs_i = self.cnt_raw.copy()
-        yy = o.filtrar(st, self.y_raw.copy())
+        # (live columns only: with nothing to prune the reference indexes its unsliced (2,L) map
+        # with a length-Lact mask and raises, scripts/ICM_SLAM_tools.py:259 -- DESIGN.md section 2)
+        yy = o.filtrar(st, self.y_raw[:, :self.lact_raw].copy())
         self.lact = st.landmarks_actuales
         self.map = yy[:, :self.lact].copy()
         self.counts = st.cant_obs_i
