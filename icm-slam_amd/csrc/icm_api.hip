@@ -28,11 +28,11 @@ std::string g_create_err;
 
 enum KernelId {
     KID_PREFILTER = 0, KID_SCAN, KID_ASSOC_BRUTE, KID_ASSOC_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_TOTALS,
-    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_FILTRAR, KID_NEIGH, KID_CHUNK_L1, KID_CHUNK_L2, KID_LM_L3, KID_REC_PUSH, KID_COUNT
+    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_SOLVE_DEFERRED, KID_FILTRAR, KID_NEIGH, KID_CHUNK_L1, KID_CHUNK_L2, KID_LM_L3, KID_REC_PUSH, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_scan", "k_associate_brute", "k_assoc_group", "k_compact",
                                        "radix_sort_pairs", "k_lm_bounds", "k_lm_scan_totals", "k_stats_prefix",
-                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_filtrar_grid", "k_neigh_table",
+                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_solve_deferred", "k_filtrar_grid", "k_neigh_table",
                                        "k_chunk_l1", "k_chunk_l2", "k_lm_l3", "k_rec_push"};
 
 template <class T>
@@ -117,9 +117,11 @@ struct icm_handle {
         int64_t K = 0, lact = 0;
         bool h_map_valid = true, valid = false;
     } snap;
-    DevBuf<int> solve_flags;  // per-wave completion flags of the fused red-black solve (+1: error word)
+    DevBuf<int> solve_flags;  // fused red-black solve: [nw] completion flags of the odd waves | [nw] deferred marks of the even waves
+    DevBuf<unsigned long long> solve_ndef;   // even waves that deferred to the fix-up launch, over the handle's life
+    int solve_flag_waves = 0;
     int solve_epoch = 0;
-    bool fused_used = false;
+    int fused_spin_limit = 1 << 17;   // polls (x ~0.2 us) an even wave waits for its odd neighbours before deferring
     bool ms_clean = false;   // the [superchunk x L] matrix is zero (cleared on the side stream under the solves)
     int fuse_colours = 1;    // 1: both colours of an unsharded red-black sweep in one launch (k_solve_m_fused)
     int entry_path = -1;     // -1 automatic, 0 sort-based pipeline, 1 hierarchical (falls back when a table overflows)
@@ -265,7 +267,7 @@ int icm_destroy(icm_handle* h) {
     h->e_key.release();
     h->skey.release();
     h->sort_tmp.release();
-    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release();
+    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release(); h->solve_ndef.release();
     h->snap.x.release(); h->snap.mapx.release(); h->snap.mapy.release(); h->snap.counts_new.release();
     h->snap.g_cell.release(); h->snap.g_lm.release(); h->snap.g_nb.release(); h->snap.gpar.release();
     if (h->pin_i) (void)hipHostFree(h->pin_i);
@@ -491,18 +493,6 @@ static int edge_last(const icm_handle* h) {
     return (int)std::min<int64_t>(std::max<int64_t>(h->t_begin + h->nloc - 1, 0), std::max<int64_t>(h->T - 1, 0));
 }
 
-// Call after the main stream has been synchronised: did an even wave of the last fused red-black
-// solve give up waiting for its odd neighbours?
-static int check_fused(icm_handle* h) {
-    if (!h->fused_used) return ICM_OK;
-    h->fused_used = false;
-    if (h->pin_i[4]) {
-        h->pin_i[4] = 0;
-        FAIL(h, ICM_ERR_HIP, "fused red-black solve: a wave timed out waiting for its neighbours (icm_set_colour_fusion(h, 0) selects two launches)");
-    }
-    return ICM_OK;
-}
-
 // this rank's slot of the landmark statistics: the send buffer if one is bound
 static double* stats_slot(icm_handle* h) {
     return h->stats_send ? h->stats_send : h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h);
@@ -649,10 +639,6 @@ int icm_sweep_local(icm_handle* h) {
             HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        {
-            int rcf = check_fused(h);   // (the previous sweep's solves are behind this synchronisation too)
-            if (rcf) return rcf;
-        }
         if (h->pin_i[2] && h->hash_slots == 128) {  // a scan with > 96 distinct landmarks: use the larger table from now on
             h->hash_slots = 256;
             HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
@@ -811,19 +797,23 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         const bool quad = h->solve_quad == 1 || (h->solve_quad < 0 && npc * 4 <= (int64_t)1024 * kWave);
         const int ppw = quad ? kWave / 4 : kWave;
         const int nwv = (int)((npc + ppw - 1) / ppw);
-        if (h->solve_flags.cap < (size_t)nwv) {
-            HIPCHK(h, h->solve_flags.reserve((size_t)nwv));
-            HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, (size_t)nwv * sizeof(int), h->stream));
+        if (h->solve_flag_waves < nwv) {
+            HIPCHK(h, h->solve_flags.reserve(2 * (size_t)nwv));
+            HIPCHK(h, h->solve_ndef.reserve(1));
+            HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, 2 * (size_t)nwv * sizeof(int), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->solve_ndef.p, 0, sizeof(unsigned long long), h->stream));
+            h->solve_flag_waves = nwv;
             h->solve_epoch = 0;
         }
         ++h->solve_epoch;   // (flags hold the epoch of the launch that set them: no reset between launches)
-        h->fused_used = true;
-        h->pin_i[4] = 0;   // (pinned host memory, mapped into the device: a wave that gives up waiting writes 1 here)
-        // test hook for the give-up path: the odd waves publish a stale epoch, every even wave times out
-        static const bool stall = std::getenv("ICMSLAM_TEST_STALL_FUSED") != nullptr;
-        const int publish = stall ? h->solve_epoch - 1 : h->solve_epoch;
-        if (quad) TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, publish, h->pin_i_dev + 4)));
-        else TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, publish, h->pin_i_dev + 4)));
+        int* const deferred = h->solve_flags.p + h->solve_flag_waves;
+        if (quad) {
+            TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->fused_spin_limit, deferred)));
+            TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_deferred<true><<<nblocks_waves(nwv), kBlock, 0, h->stream>>>(a, nwv, deferred, h->solve_ndef.p)));
+        } else {
+            TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->fused_spin_limit, deferred)));
+            TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_deferred<false><<<nblocks_waves(nwv), kBlock, 0, h->stream>>>(a, nwv, deferred, h->solve_ndef.p)));
+        }
     } else if (schedule == ICM_SCHEDULE_REDBLACK) {
         const int nw = (int)(h->nloc / 2 + 1);
         for (int col = 1; col >= 0; --col) {
@@ -885,10 +875,6 @@ int icm_sweep_finish(icm_handle* h) {
         return ICM_OK;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    {
-        int rcf = check_fused(h);
-        if (rcf) return rcf;
-    }
     std::vector<double> yo(2 * L), co(L);
     int64_t lact_new = 0;
     int rc = filtrar_host(h->cfg, h->h_yraw.data(), h->h_cntraw.data(), h->lact_raw, yo.data(), co.data(), &lact_new, h->err);
@@ -987,10 +973,6 @@ int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out,
         std::vector<double> xt(3 * T);
         HIPCHK(h, hipMemcpyAsync(xt.data(), h->x, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        {
-            int rcf = check_fused(h);
-            if (rcf) return rcf;
-        }
         for (size_t t = 0; t < T; ++t) {
             x[t] = xt[3 * t];
             x[T + t] = xt[3 * t + 1];
@@ -1241,6 +1223,25 @@ int icm_set_solve_lanes(icm_handle* h, int mode) {
 int icm_set_colour_fusion(icm_handle* h, int on) {
     if (!h) return ICM_ERR_ARG;
     h->fuse_colours = on != 0;
+    return ICM_OK;
+}
+
+int icm_set_fused_spin_limit(icm_handle* h, int polls) {
+    if (!h) return ICM_ERR_ARG;
+    if (polls < 0) FAIL(h, ICM_ERR_ARG, "icm_set_fused_spin_limit: polls must be >= 0");
+    h->fused_spin_limit = polls;
+    return ICM_OK;
+}
+
+int icm_get_fused_deferred(icm_handle* h, int64_t* waves) {
+    if (!h || !waves) return ICM_ERR_ARG;
+    *waves = 0;
+    if (!h->solve_ndef.p) return ICM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long v = 0;
+    HIPCHK(h, hipMemcpyAsync(&v, h->solve_ndef.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *waves = (int64_t)v;
     return ICM_OK;
 }
 

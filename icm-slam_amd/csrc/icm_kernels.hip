@@ -1858,40 +1858,24 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
 // sequence (which is what a kernel boundary between the colours does) but only for the two odd
 // waves that hold its poses' neighbours.  Waves [0, nw) solve the odd poses and publish a
 // per-wave flag; waves [nw, 2 nw) poll the two flags they depend on, then solve the even poses.
-// The odd waves have the lower workgroup ids, are dispatched first and never wait, so the grid
-// always drains; a poll that sees nothing for seconds gives up and raises err[0].
+//
+// Forward progress does NOT rest on dispatch order: an even wave polls at most `spin_limit`
+// times; if its flags have not arrived by then it marks itself in `deferred[]`, touches nothing
+// and exits (freeing its slot for whatever odd waves are still waiting to be dispatched).
+// k_solve_m_deferred, launched right behind on the same stream, solves exactly the marked waves
+// -- behind the kernel boundary every odd pose is final -- and clears the marks.  With the
+// observed dispatch (lower workgroup ids first) no wave ever defers and that launch is empty;
+// under any other dispatch order the sweep is slower, never wrong and never stuck.
 // Hand-off per MI355X_MICROARCH.md: producer = plain stores, vmcnt(0), agent release fence,
 // vmcnt(0), relaxed agent flag store; consumer = relaxed polls, ONE agent acquire fence,
 // vmcnt(0), then plain loads.  The odd waves that READ an even wave's poses (as the old values of
 // their neighbours) are exactly the two it waits for, so nothing is overwritten while in use.
 // QUAD: the latency form (one DPP quad per pose, 16 poses per wave) with the same dependency rule.
 template <bool QUAD>
-__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, int* __restrict__ flags, int epoch,
-                                                          int publish, int* __restrict__ err) {
+__device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, bool even, int wv, int lane) {
     constexpr int PPW = QUAD ? kWave / 4 : kWave;   // poses per wave
-    const int lane = lane_id();
-    const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
-    if (gw >= 2 * nw) return;
-    const bool even = gw >= nw;
-    const int wv = even ? gw - nw : gw;
     const int role = QUAD ? (lane & 3) : 0;
     const int tg = (even ? 2 : 1) + 2 * (wv * PPW + (QUAD ? lane >> 2 : lane));   // (unsharded: t_begin = 0)
-    if (even) {
-        if (lane == 0) {
-            for (int d = 0; d < 2 && wv + d < nw; ++d) {   // odd poses 2j+1, j in [PPW wv, PPW wv + PPW]
-                int spins = 0;
-                while (__hip_atomic_load(&flags[wv + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 22)) {   // (seconds: a legitimate wait is at most the length of the launch)
-                        *reinterpret_cast<volatile int*>(err) = 1;   // (host-pinned word)
-                        break;
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     if (tg < a.nloc) {   // (whole quads together)
         double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
         double res[3];
@@ -1902,11 +1886,57 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, i
             a.x[3 * (size_t)tg + 2] = res[2];
         }
     }
+}
+
+template <bool QUAD>
+__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, int* __restrict__ flags, int epoch,
+                                                          int spin_limit, int* __restrict__ deferred) {
+    const int lane = lane_id();
+    const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (gw >= 2 * nw) return;
+    const bool even = gw >= nw;
+    const int wv = even ? gw - nw : gw;
+    if (even) {
+        int ready = 1;
+        if (lane == 0) {
+            for (int d = 0; d < 2 && wv + d < nw && ready; ++d) {   // odd poses 2j+1, j in [PPW wv, PPW wv + PPW]
+                int spins = 0;
+                while (__hip_atomic_load(&flags[wv + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    if (++spins > spin_limit) {
+                        ready = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            if (!ready) deferred[wv] = 1;   // (read by the next launch: a kernel boundary, no fence needed)
+        }
+        ready = __builtin_amdgcn_readfirstlane(ready);
+        if (!ready) return;                 // wave-uniform: x is left untouched
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    solve_wave_poses<QUAD>(a, even, wv, lane);
     if (!even) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&flags[wv], publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (= epoch)
+        if (lane == 0) __hip_atomic_store(&flags[wv], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The even waves k_solve_m_fused deferred (normally none: every wave returns at once).
+template <bool QUAD>
+__global__ __launch_bounds__(kBlock) void k_solve_m_deferred(SolveArgs a, int nw, int* __restrict__ deferred,
+                                                             unsigned long long* __restrict__ n_deferred) {
+    const int lane = lane_id();
+    const int wv = blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (wv >= nw) return;
+    if (!deferred[wv]) return;
+    solve_wave_poses<QUAD>(a, true, wv, lane);
+    if (lane == 0) {
+        deferred[wv] = 0;
+        atomicAdd(n_deferred, 1ull);
     }
 }
 

@@ -355,6 +355,16 @@ class SweepEngine:
         """True (default): both colours of an unsharded red-black sweep in one launch."""
         self._chk(self.lib.icm_set_colour_fusion(self.h, int(bool(on))))
 
+    def set_fused_spin_limit(self, polls):
+        """Polls an even wave of the one-launch solve waits before deferring to the fix-up launch."""
+        self._chk(self.lib.icm_set_fused_spin_limit(self.h, int(polls)))
+
+    def fused_deferred(self):
+        """Even waves that deferred to the fix-up launch so far (normally 0)."""
+        n = C.c_int64(0)
+        self._chk(self.lib.icm_get_fused_deferred(self.h, C.byref(n)))
+        return int(n.value)
+
     def set_entry_path(self, mode):
         """-1 / 1 / 'hier': hierarchical running sums (default); 0 / 'sort': the sort-based pipeline."""
         mode = {"hier": 1, "sort": 0, "auto": -1}.get(mode, mode)

@@ -216,6 +216,15 @@ int icm_set_solve_lanes(icm_handle *h, int mode);
  * even wave starting as soon as the two odd waves holding its poses' neighbours are done
  * (k_solve_m_fused); 0 = one launch per colour.  Bit-identical results. */
 int icm_set_colour_fusion(icm_handle *h, int on);
+/* How many times an even wave of the one-launch solve polls for its odd neighbours (~0.2 us per
+ * poll; default 1 << 17) before it DEFERS: it leaves its poses untouched and the fix-up launch
+ * queued right behind (k_solve_m_deferred) solves them after the kernel boundary.  Forward
+ * progress therefore never depends on the order workgroups are dispatched in; 0 defers every wave
+ * whose neighbours are not done at its first look (= one launch per colour, through the same
+ * code).  Bit-identical results for every value.  icm_get_fused_deferred: waves deferred so far
+ * over the handle's life (synchronises the stream). */
+int icm_set_fused_spin_limit(icm_handle *h, int polls);
+int icm_get_fused_deferred(icm_handle *h, int64_t *waves);
 
 /* Pipeline that turns the per-pose entries into running-mean targets (the time-ordered
  * per-landmark prefix of Mapa.actualizar, scripts/ICM_SLAM_tools.py:184-196):
