@@ -16,7 +16,7 @@ constexpr int kWave = 64;
 
 // 1 only in eval_probe.hip (tools/count_eval_flops.py): the rarely taken slow paths (fmod in
 // wrap_pi, generic sincos beyond |d| = 0.25) are compiled out so that the probe's ISA is the
-// straight-line path an energy evaluation executes.
+// straight-line path an energy evaluation executes with the default isotropic Q.
 #ifndef ICM_PROBE_FAST_TRIG_ONLY
 #define ICM_PROBE_FAST_TRIG_ONLY 0
 #endif
@@ -74,6 +74,12 @@ struct SolveCtx {
     double o2x, o2y, o2t;
     // weights
     double dt, R0, R1, R2, Q0, Q1, cte;
+    // moment-form energy only (make_ctx): centre of the previous-pose odometry term, a_xy +
+    // Rot(a)^T o1 (|o1 - Rot(a) d|^2 = |d - Rot(a)^T o1|^2: a rotation keeps the norm), and the
+    // products dt v, dt w of the unicycle step
+    // wn = 1 (two-sided, fun_xn) or 0 (one-sided, fun_x): weight of the next-pose terms;
+    // o2tp = o2t - xpt
+    double hx, hy, dtv, dtw, wn, o2tp;
 };
 
 // Observation items of one pose.  Two forms of the same energy h(x):
@@ -165,6 +171,8 @@ struct PoseMoments {
     double cxx, cxy, cyy;      // pooled within-entry scatter (body frame)
     double sc_iso;             // Q0 (cxx + cyy): the scatter term when Q is isotropic
     double pox, poy, tho, co, so;   // expansion point: p_o, th_o, cos/sin th_o
+    // isotropic Q (finish_moments): (Swxrx + Swyry) - (Swxx + Swyy), Swxry - Swyrx, Srxx + Sryy
+    double AW, Bq, Rr;
 };
 constexpr int kMomentCount = 14;
 
@@ -188,38 +196,73 @@ __device__ __forceinline__ void small_sincosm1(double d, double& s, double& cm1)
     cm1 = -(z * pc);                                                        // -d^2/2 + d^4/24 - ...
 }
 
+// Derived sums of the isotropic form (Q0 == Q1): with X, Y the two quadratic forms below,
+//   X + Y = S (dx^2 + dy^2) + Rr + 2 [dx (al Swx - be Swy + Srx) + dy (al Swy + be Swx + Sry) + al AW + be Bq]
+// because the al be Swxy terms cancel and al^2 + be^2 = (cos d - 1)^2 + sin^2 d = -2 al exactly.
+__device__ __forceinline__ void finish_moments(const SolveCtx& c, PoseMoments& m) {
+    m.sc_iso = c.Q0 * (m.cxx + m.cyy);
+    m.AW = (m.Swxrx + m.Swyry) - (m.Swxx + m.Swyy);
+    m.Bq = m.Swxry - m.Swyrx;
+    m.Rr = m.Srxx + m.Sryy;
+}
+
+// The moment-form energy is the build's own arithmetic -- an exact regrouping of the reference's
+// per-beam sum, not its expression tree -- so it may use fused multiply-adds.  They are written
+// out (fma_) instead of left to `fp contract`: every kernel form (lane, quad, sequential,
+// fast and generic path) then rounds identically by construction.
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // Observation energy in moment form at (px, py) and heading th_o + d, given
-// al = cos d - 1 and be = sin d, and (for the scatter term) cos/sin of the heading.
+// al = cos d - 1 and be = sin d, and (anisotropic Q only) cos/sin of the heading.
 __device__ __forceinline__ double moments_energy(const SolveCtx& c, const PoseMoments& m, double px, double py,
                                                  double al, double be, double cth, double sth) {
     const double dx = px - m.pox, dy = py - m.poy;
+    if (ICM_PROBE_FAST_TRIG_ONLY || c.Q0 == c.Q1) {   // (wave-uniform: the weights are kernel arguments; the probe counts this path)
+        const double g1 = fma_(al, m.Swx, fma_(-be, m.Swy, m.Srx));
+        const double g2 = fma_(al, m.Swy, fma_(be, m.Swx, m.Sry));
+        const double cross = fma_(dx, g1, fma_(dy, g2, fma_(al, m.AW, be * m.Bq)));
+        const double rr = fma_(dx, dx, dy * dy);
+        return fma_(c.Q0, fma_(2.0, cross, fma_(m.S, rr, m.Rr)), m.sc_iso);
+    }
     const double X = (((m.S * dx) * dx + (al * al) * m.Swxx) + ((be * be) * m.Swyy + m.Srxx)) +
                      2.0 * ((dx * ((al * m.Swx - be * m.Swy) + m.Srx) + al * (m.Swxrx - be * m.Swxy)) - be * m.Swyrx);
     const double Y = (((m.S * dy) * dy + (al * al) * m.Swyy) + ((be * be) * m.Swxx + m.Sryy)) +
                      2.0 * ((dy * ((al * m.Swy + be * m.Swx) + m.Sry) + al * (m.Swyry + be * m.Swxy)) + be * m.Swxry);
-    // scatter term tr(R^T Q R C) with cos(th - pi/2) = sin th, sin(th - pi/2) = -cos th; for an
-    // isotropic Q it does not depend on the pose: Q0 (cxx + cyy), precomputed in m.sc_iso
-    double sc = m.sc_iso;
-    if (c.Q0 != c.Q1) {
-        const double ct = sth, st = -cth;
-        sc = ((c.Q0 * ct * ct + c.Q1 * st * st) * m.cxx + 2.0 * (ct * st) * (c.Q1 - c.Q0) * m.cxy) +
-             (c.Q0 * st * st + c.Q1 * ct * ct) * m.cyy;
-    }
+    // scatter term tr(R^T Q R C) with cos(th - pi/2) = sin th, sin(th - pi/2) = -cos th
+    const double ct = sth, st = -cth;
+    const double sc = ((c.Q0 * ct * ct + c.Q1 * st * st) * m.cxx + 2.0 * (ct * st) * (c.Q1 - c.Q0) * m.cxy) +
+                      (c.Q0 * st * st + c.Q1 * ct * ct) * m.cyy;
     return (c.Q0 * X + c.Q1 * Y) + sc;
 }
 
-// fun_xn / fun_x with h in moment form.  Trigonometry: the NM iterates stay within a fraction
-// of a radian of the pose's previous heading th_o, so sin d, cos d - 1 come from short
-// polynomials and cos th, sin th from the rotation of (cos th_o, sin th_o) by d; the generic
-// sincos path is kept for |d| > 0.25 (the initial simplex vertex th*1.05 of a long trajectory).
-__device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const PoseMoments& m, double px, double py,
-                                                      double th) {
-    const double dl = th - m.tho;
+// entrepi for |a| < 2 pi without the fmod: the two conditional shifts as selects.
+__device__ __forceinline__ double wrap_small(double a) {
+    const double r = a < 0.0 ? a + kTwoPi : a;
+    return r > kPi ? r - kTwoPi : r;
+}
+
+// fun_xn / fun_x with h in moment form (reference scripts/ICM_ROS.py:220-278, Appendix A.4).
+// Trigonometry: the NM iterates stay within a fraction of a radian of the pose's previous heading
+// th_o, so sin d, cos d - 1 come from short polynomials and cos th, sin th from the rotation of
+// (cos th_o, sin th_o) by d.  The angle residuals keep the reference's operation order (the wrap
+// adds and subtracts 2 pi, which is not the identity in floating point); the planar terms are
+// regrouped:
+//   previous-pose odometry  |o1 - Rot(a)(p - a)|^2 = |p - (a + Rot(a)^T o1)|^2   (c.hx, c.hy)
+//   unicycle step           g(x).xy - b.xy = (p - b.xy) + (dt v) (cos th, sin th)
+// A one-sided energy (fun_x: last pose, c.wn = 0) multiplies the next-pose terms by zero:
+// ((0 + prevR) + hh) + prevO is the reference's (prevR + hh) + prevO bit for bit.
+// GENERIC = false: straight-line code, valid while |d| <= 0.25 and every wrapped angle is inside
+// (-2 pi, 2 pi); GENERIC = true: the same expressions with the rare cases (generic sincos, fmod)
+// selected per lane.  pose_energy_moments() takes the generic road for a whole wavefront when any
+// of its lanes needs it, so the common case has no divergent branch at all.
+template <bool GENERIC>
+__device__ __forceinline__ double pose_energy_moments_t(const SolveCtx& c, const PoseMoments& m, double px, double py,
+                                                        double th, double dl, double a0, double a1, double a2, double a3) {
     double cth, sth, al, be;
-    if (ICM_PROBE_FAST_TRIG_ONLY || fabs(dl) <= 0.25) {
+    if (!GENERIC || fabs(dl) <= 0.25) {
         small_sincosm1(dl, be, al);
-        cth = m.co + (m.co * al - m.so * be);
-        sth = m.so + (m.so * al + m.co * be);
+        cth = m.co + fma_(m.co, al, -(m.so * be));
+        sth = m.so + fma_(m.so, al, m.co * be);
     } else {
         sth = sin(th);
         cth = cos(th);
@@ -229,23 +272,36 @@ __device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const P
         al = den > 1e-3 ? -(be * be) / den : cd - 1.0;  // cos d - 1 without cancellation
     }
     const double hh = moments_energy(c, m, px, py, al, be, cth, sth);
-    const double r0 = px - c.gax, r1 = py - c.gay, r2 = wrap_pi(th - c.gat);
-    const double prevR = ((r0 * c.R0) * r0 + (r1 * c.R1) * r1) + (r2 * c.R2) * r2;
-    const double dax = px - c.xax, day = py - c.xay;
-    const double q0 = c.o1x - (c.ca * dax + c.sa * day);
-    const double q1 = c.o1y - (-c.sa * dax + c.ca * day);
-    const double q2 = wrap_pi((c.o1t - th) + c.xat);
-    const double prevO = c.cte * ((q0 * q0 + q1 * q1) + q2 * q2);
-    if (!c.two_sided) return (prevR + hh) + prevO;
-    const double gx = px + c.dt * (cth * c.v), gy = py + c.dt * (sth * c.v), gt = th + c.dt * c.w;
-    const double s0 = gx - c.xpx, s1 = gy - c.xpy, s2 = wrap_pi(gt - c.xpt);
-    const double nextR = ((s0 * c.R0) * s0 + (s1 * c.R1) * s1) + (s2 * c.R2) * s2;
+    const double r0 = px - c.gax, r1 = py - c.gay, r2 = GENERIC ? wrap_pi(a0) : wrap_small(a0);
+    const double prevR = fma_(r0 * c.R0, r0, fma_(r1 * c.R1, r1, (r2 * c.R2) * r2));
+    const double q0 = px - c.hx, q1 = py - c.hy, q2 = GENERIC ? wrap_pi(a1) : wrap_small(a1);
+    const double prevO = c.cte * fma_(q0, q0, fma_(q1, q1, q2 * q2));
+    const double s0 = fma_(c.dtv, cth, px - c.xpx), s1 = fma_(c.dtv, sth, py - c.xpy), s2 = GENERIC ? wrap_pi(a2) : wrap_small(a2);
+    const double nextR = fma_(s0 * c.R0, s0, fma_(s1 * c.R1, s1, (s2 * c.R2) * s2));
     const double ex = c.xpx - px, ey = c.xpy - py;
-    const double p0 = c.o2x - (cth * ex + sth * ey);
-    const double p1 = c.o2y - (-sth * ex + cth * ey);
-    const double p2 = wrap_pi((c.o2t - c.xpt) + th);
-    const double nextO = c.cte * ((p0 * p0 + p1 * p1) + p2 * p2);
-    return (((nextR + nextO) + prevR) + hh) + prevO;
+    const double p0 = c.o2x - fma_(cth, ex, sth * ey);
+    const double p1 = c.o2y - fma_(cth, ey, -(sth * ex));
+    const double p2 = GENERIC ? wrap_pi(a3) : wrap_small(a3);
+    const double nextO = c.cte * fma_(p0, p0, fma_(p1, p1, p2 * p2));
+    return ((c.wn * (nextR + nextO) + prevR) + hh) + prevO;
+}
+
+__device__ __noinline__ double pose_energy_moments_generic(const SolveCtx& c, const PoseMoments& m, double px, double py,
+                                                           double th, double dl, double a0, double a1, double a2, double a3) {
+    return pose_energy_moments_t<true>(c, m, px, py, th, dl, a0, a1, a2, a3);
+}
+
+__device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const PoseMoments& m, double px, double py,
+                                                      double th) {
+    const double dl = th - m.tho;
+    const double a0 = th - c.gat;              // prev: model residual angle
+    const double a1 = (c.o1t - th) + c.xat;    // prev: odometry residual angle
+    const double a2 = (th + c.dtw) - c.xpt;    // next: model residual angle
+    const double a3 = c.o2tp + th;             // next: odometry residual angle, (o2t - xpt) + th
+    const bool fast = (int)(fabs(dl) <= 0.25) & (int)(fabs(a0) < kTwoPi) & (int)(fabs(a1) < kTwoPi) & (int)(fabs(a2) < kTwoPi) & (int)(fabs(a3) < kTwoPi);
+    if (!ICM_PROBE_FAST_TRIG_ONLY && __builtin_expect(__ballot(!fast) != 0ull, 0))
+        return pose_energy_moments_generic(c, m, px, py, th, dl, a0, a1, a2, a3);
+    return pose_energy_moments_t<false>(c, m, px, py, th, dl, a0, a1, a2, a3);
 }
 
 // fun_xn (two_sided) / fun_x (reference scripts/ICM_ROS.py:220-278), Appendix A.4, given
@@ -298,14 +354,20 @@ __device__ __forceinline__ void make_ctx(SolveCtx& c, int two_sided, const doubl
     c.o1x = coa * d1x + soa * d1y;
     c.o1y = -soa * d1x + coa * d1y;
     c.o1t = ot[2] - oa[2];
+    c.hx = xa[0] + (c.ca * c.o1x - c.sa * c.o1y);
+    c.hy = xa[1] + (c.sa * c.o1x + c.ca * c.o1y);
+    c.dtv = c.dtw = c.o2tp = 0.0;
+    c.wn = two_sided ? 1.0 : 0.0;
     if (two_sided) {
         c.xpx = xp[0]; c.xpy = xp[1]; c.xpt = xp[2];
         c.v = ut[0]; c.w = ut[1];
+        c.dtv = c.dt * ut[0]; c.dtw = c.dt * ut[1];
         const double cot = cos(ot[2]), sot = sin(ot[2]);
         const double d2x = op[0] - ot[0], d2y = op[1] - ot[1];
         c.o2x = cot * d2x + sot * d2y;
         c.o2y = -sot * d2x + cot * d2y;
         c.o2t = op[2] - ot[2];
+        c.o2tp = c.o2t - c.xpt;
     } else {
         c.xpx = c.xpy = c.xpt = c.v = c.w = c.o2x = c.o2y = c.o2t = 0.0;
     }
@@ -314,6 +376,18 @@ __device__ __forceinline__ void make_ctx(SolveCtx& c, int two_sided, const doubl
 struct Vtx {
     double x, y, t, f;
 };
+
+// x / 3.0 correctly rounded without the division sequence (v_div_scale, v_rcp, Newton steps,
+// v_div_fmas, v_div_fixup): with z = RN(1/3), q = RN(x z) is within an ulp of x/3, the residual
+// r = x - 3 q is exact in one fma, and RN(q + r z) is the correctly rounded quotient (Markstein's
+// theorem; checked against x / 3.0 on 4e8 random doubles) -- bit-identical to numpy's
+// `np.add.reduce(sim[:-1], 0) / N` for every finite x that does not underflow.
+__device__ __forceinline__ double div3(double x) {
+    const double z = 1.0 / 3.0;
+    const double q = x * z;
+    const double r = __builtin_fma(-3.0, q, x);
+    return __builtin_fma(r, z, q);
+}
 
 __device__ __forceinline__ void cswap(Vtx& a, Vtx& b) {
     if (b.f < a.f) {
@@ -374,9 +448,9 @@ __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double s
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
         if (dx <= xatol && df <= fatol) break;
-        const double bx = ((v0.x + v1.x) + v2.x) / 3.0;
-        const double by = ((v0.y + v1.y) + v2.y) / 3.0;
-        const double bt = ((v0.t + v1.t) + v2.t) / 3.0;
+        const double bx = div3((v0.x + v1.x) + v2.x);
+        const double by = div3((v0.y + v1.y) + v2.y);
+        const double bt = div3((v0.t + v1.t) + v2.t);
         Vtx r{2 * bx - v3.x, 2 * by - v3.y, 2 * bt - v3.t, 0.0};
         r.f = f(r.x, r.y, r.t);
         ++nfev;
@@ -480,9 +554,9 @@ __device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, dou
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
         if (dx <= xatol && df <= fatol) break;
-        const double bx = ((v0.x + v1.x) + v2.x) / 3.0;
-        const double by = ((v0.y + v1.y) + v2.y) / 3.0;
-        const double bt = ((v0.t + v1.t) + v2.t) / 3.0;
+        const double bx = div3((v0.x + v1.x) + v2.x);
+        const double by = div3((v0.y + v1.y) + v2.y);
+        const double bt = div3((v0.t + v1.t) + v2.t);
         // my point (role 0: 2*xbar - sim[-1], written so that it rounds like the scalar form)
         const double mx = role == 0 ? 2 * bx - v3.x : ca * bx + cb * v3.x;
         const double my = role == 0 ? 2 * by - v3.y : ca * by + cb * v3.y;

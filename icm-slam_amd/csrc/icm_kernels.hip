@@ -1811,7 +1811,7 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
     m.Swxx = pm[5 * st_]; m.Swyy = pm[6 * st_]; m.Swxy = pm[7 * st_]; m.Swxrx = pm[8 * st_]; m.Swyrx = pm[9 * st_];
     m.Swxry = pm[10 * st_]; m.Swyry = pm[11 * st_]; m.Srxx = pm[12 * st_]; m.Sryy = pm[13 * st_];
     m.cxx = pm[14 * st_]; m.cxy = pm[15 * st_]; m.cyy = pm[16 * st_];
-    m.sc_iso = c.Q0 * (m.cxx + m.cyy);
+    finish_moments(c, m);
     // expansion point = this pose's previous-sweep value (still in x: nobody else writes it)
     m.pox = a.x[3 * (size_t)tg]; m.poy = a.x[3 * (size_t)tg + 1];
     m.tho = a.x[3 * (size_t)tg + 2];
