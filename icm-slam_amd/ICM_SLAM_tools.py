@@ -1,9 +1,10 @@
 """Drop-in counterpart of the reference's `scripts/ICM_SLAM_tools.py` (== `scripts/ICM_SLAM.py`)
 for the MI355X-native build: the same names (`ConfigICM`, `Mapa`, `ROS`, `Sensor`, `filtrar_z`,
-`tras_rot_z`, `Rota`, `entrepi`, `calc_cambio`, plotting helpers), the same argument meaning
+`tras_rot_z`, `Rota`, `entrepi`, `calc_cambio`), the same argument meaning
 and error behaviour, so `from ICM_SLAM_tools import *` in a driver keeps working.
 
-What is NOT here: the arithmetic of the sweep.  `filtrar_z`, the association/running-mean of
+What is NOT here: the reference's matplotlib helpers (`graficar*`: visualisation, out of scope,
+SURVEY section 2) and the arithmetic of the sweep.  `filtrar_z`, the association/running-mean of
 `Mapa.actualizar` and the map prune/merge of `Mapa.filtrar` run inside the HIP library
 (`icmslam_hip`); the methods below are thin calls into it.  There is no NumPy fallback.
 """
@@ -75,8 +76,9 @@ class ConfigICM:
 
 class Mapa:
     """State of the landmark map between sweeps (reference scripts/ICM_SLAM_tools.py:104-265):
-    `landmarks_actuales`, `cant_obs_i`.  Inside a sweep the per-scan update (`actualizar`) is
-    fused into the HIP kernels; `filtrar` is the library's host routine."""
+    `landmarks_actuales`, `cant_obs_i`.  Inside a sweep the per-scan update is fused into the HIP
+    kernels; `actualizar` is the same step for one scan (`icm_associate`), `filtrar` the library's
+    map prune/merge."""
 
     def __init__(self, config):
         self.config = config
@@ -99,9 +101,22 @@ class Mapa:
         return yo
 
     def actualizar(self, mapa, mapa_referencia, obs):
-        raise NotImplementedError(
-            "Mapa.actualizar is fused into the HIP sweep (phase A/B kernels); call "
-            "ICM_ROS.iterations_process_offline instead of updating the map scan by scan")
+        """One scan into the running map (reference scripts/ICM_SLAM_tools.py:128-201): `obs` (n,2)
+        world points are matched to the columns of `mapa_referencia[:, :landmarks_actuales]` (the
+        first call, with no landmark yet, clusters the scan instead), gated at `dist_thr`; `mapa`
+        (2,L) and `cant_obs_i` take the running-mean update.  Returns (mapa, c) like the reference:
+        `mapa` is updated in place and returned, `c` are the labels.  Inside a sweep this step is
+        fused into the phase A/B kernels; this is the per-scan call of the online initialisation
+        (scripts/ICM_ROS.py:114), through `icm_associate`."""
+        inplace = isinstance(mapa, np.ndarray) and mapa.dtype == np.float64 and mapa.flags.c_contiguous
+        mw = mapa if inplace else np.ascontiguousarray(mapa, dtype=np.float64)
+        if not (isinstance(self.cant_obs_i, np.ndarray) and self.cant_obs_i.dtype == np.float64 and self.cant_obs_i.flags.c_contiguous):
+            self.cant_obs_i = np.ascontiguousarray(self.cant_obs_i, dtype=np.float64)
+        c, lact = _engine.actualizar_scan(self.config, mw, mapa_referencia, obs, self.landmarks_actuales, self.cant_obs_i)
+        if not inplace:
+            mapa[...] = mw
+        self.landmarks_actuales = lact
+        return mapa, c
 
 
 def filtrar_z(z, config):
@@ -173,38 +188,3 @@ class Sensor:
         self.topic_msg = topic_msg
         self.principalCallback = principalCallback
         self.c = 0
-
-
-def graficar(x, yy, odometria, N=0):
-    import matplotlib.pyplot as plt
-    plt.figure(N)
-    plt.plot(x[0], x[1], "b")
-    plt.plot(odometria[0], odometria[1], "g")
-    plt.plot(yy[0], yy[1], "b*")
-    plt.axis("equal")
-    plt.show()
-
-
-class graficar2:
-    def data(self, x, yy, odometria, N=0):
-        import matplotlib.pyplot as plt
-        plt.figure(N)
-        plt.clf()
-        plt.plot(x[0], x[1], "b")
-        plt.plot(odometria[0], odometria[1], "g")
-        plt.plot(yy[0], yy[1], "b*")
-        plt.axis("equal")
-        plt.pause(0.01)
-
-    def show(self):
-        import matplotlib.pyplot as plt
-        plt.show()
-
-
-def graficar_cambio(cambios_minimos, cambios_maximos, cambios_medios):
-    import matplotlib.pyplot as plt
-    plt.figure(100)
-    plt.plot(cambios_minimos, "b--")
-    plt.plot(cambios_maximos, "b--")
-    plt.plot(cambios_medios, "b")
-    plt.show()

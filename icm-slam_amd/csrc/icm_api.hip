@@ -1113,6 +1113,93 @@ int icm_cluster_first_scan(const double* pts, int64_t n, double t, int32_t* labe
     return cluster_first_scan_host(pts, n, t, labels_out, g_create_err);
 }
 
+// Mapa.actualizar for ONE scan (reference scripts/ICM_SLAM_tools.py:128-201), both branches.
+int icm_associate(icm_handle* h, const double* obs, int64_t n, const double* map_ref, int64_t K_ref, double* map,
+                  double* counts, int64_t* lact_inout, int64_t* labels_out) {
+    if (!h) return ICM_ERR_ARG;
+    if (!map || !counts || !lact_inout || (n > 0 && (!obs || !labels_out))) FAIL(h, ICM_ERR_ARG, "icm_associate: null pointer");
+    if (n < 0 || n > (1 << 24) || K_ref < 0) FAIL(h, ICM_ERR_ARG, "icm_associate: bad n / K_ref");
+    const int64_t L = h->cfg.L;
+    int64_t lact = *lact_inout;
+    if (lact < 0) FAIL(h, ICM_ERR_ARG, "icm_associate: landmarks_actuales < 0");
+    std::vector<int> lab((size_t)std::max<int64_t>(n, 1), -1);
+    if (lact == 0) {
+        // first scan ever: single-linkage clusters at dist_thr, their centres and sizes (:160-165)
+        if (n == 0) FAIL(h, ICM_ERR_ARG, "icm_associate: no observation to seed the map with (the reference's pdist/linkage raises on an empty scan)");
+        int rc = cluster_first_scan_host(obs, n, h->cfg.dist_thr, lab.data(), h->err);
+        if (rc) return rc;
+        int ncl = 0;
+        for (int64_t j = 0; j < n; ++j) ncl = std::max(ncl, lab[(size_t)j] + 1);
+        if (ncl > L) FAIL(h, ICM_ERR_INDEX, "icm_associate: more first-scan clusters than the map capacity L");
+        for (int i = 0; i < ncl; ++i) {
+            double sx = 0.0, sy = 0.0;   // np.mean(obs[c == i, :], axis=0): rows added in order, then / k
+            int64_t k = 0;
+            for (int64_t j = 0; j < n; ++j)
+                if (lab[(size_t)j] == i) {
+                    sx += obs[2 * j];
+                    sy += obs[2 * j + 1];
+                    ++k;
+                }
+            map[i] = sx / (double)k;
+            map[L + i] = sy / (double)k;
+            counts[i] = (double)k;
+        }
+        for (int64_t j = 0; j < n; ++j) labels_out[j] = lab[(size_t)j];
+        *lact_inout = ncl;
+        return ICM_OK;
+    }
+    if (n == 0) return ICM_OK;   // nothing observed: labels empty, map and counters untouched
+    // columns the scan can be matched against: mapa_referencia[:, :Lact] (numpy clamps the slice)
+    const int64_t km = std::min(lact, K_ref);
+    if (km <= 0 || !map_ref) FAIL(h, ICM_ERR_ARG, "icm_associate: empty reference map (np.amin of an empty cdist raises ValueError in the reference)");
+    HIPCHK(h, hipSetDevice(h->device));
+    DevBuf<double> dobs, dmap;
+    DevBuf<int> dlab;
+    HIPCHK(h, dobs.reserve(2 * (size_t)n));
+    HIPCHK(h, dmap.reserve(2 * (size_t)km));
+    HIPCHK(h, dlab.reserve((size_t)n));
+    HIPCHK(h, hipMemcpyAsync(dobs.p, obs, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dmap.p, map_ref, (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dmap.p + km, map_ref + K_ref, (size_t)km * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    k_scan_labels<<<nblocks_threads(n), kBlock, 0, h->stream>>>(dobs.p, (int)n, dmap.p, dmap.p + km, (int)km, h->cfg.dist_thr, dlab.p);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(lab.data(), dlab.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    dobs.release(); dmap.release(); dlab.release();
+    // every gated-out observation of the scan gets the SAME fresh label Lact: the reference clusters
+    // `ztt[:, 2:4]` of an (m, 2) array, i.e. zero-width points -> one cluster (:173-182)
+    bool anynew = false;
+    for (int64_t j = 0; j < n; ++j) anynew |= lab[(size_t)j] < 0;
+    if (anynew) {
+        if (lact >= L) FAIL(h, ICM_ERR_INDEX, "icm_associate: a new landmark does not fit in L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
+        for (int64_t j = 0; j < n; ++j)
+            if (lab[(size_t)j] < 0) lab[(size_t)j] = (int)lact;
+        ++lact;
+    }
+    // running means, label by label (:184-195): y <- sum(obs_i)/(n_i + k) + y n_i/(n_i + k); n_i += k
+    std::vector<char> done((size_t)n, 0);
+    for (int64_t j = 0; j < n; ++j) {
+        if (done[(size_t)j]) continue;
+        const int i = lab[(size_t)j];
+        double sx = 0.0, sy = 0.0;
+        int64_t k = 0;
+        for (int64_t q = j; q < n; ++q)
+            if (lab[(size_t)q] == i) {
+                sx += obs[2 * q];
+                sy += obs[2 * q + 1];
+                ++k;
+                done[(size_t)q] = 1;
+            }
+        const double nn = counts[i], tot = nn + (double)k;
+        map[i] = sx / tot + map[i] * nn / tot;
+        map[L + i] = sy / tot + map[L + i] * nn / tot;
+        counts[i] = tot;
+    }
+    for (int64_t j = 0; j < n; ++j) labels_out[j] = lab[(size_t)j];
+    *lact_inout = lact;
+    return ICM_OK;
+}
+
 int icm_init_pass(icm_handle* h, const double* x0, double* y, double* counts, int64_t* lact, double* x_out) {
     if (!h) return ICM_ERR_ARG;
     if (!h->prefiltered) FAIL(h, ICM_ERR_ARG, "icm_init_pass: call icm_upload + icm_prefilter first");

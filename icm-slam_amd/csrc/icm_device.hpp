@@ -176,23 +176,47 @@ struct PoseMoments {
 };
 constexpr int kMomentCount = 14;
 
+// The moment-form energy is the build's own arithmetic -- an exact regrouping of the reference's
+// per-beam sum, not its expression tree -- so it may use fused multiply-adds.  They are written
+// out (fma_) instead of left to `fp contract`: every kernel form (lane, quad, sequential,
+// fast and generic path) then rounds identically by construction.
+// The three-operand VOP3 form is spelled out: left to itself hipcc selects the destructive
+// two-operand v_fmac_f64 and then has to copy every loop-invariant addend (polynomial
+// coefficient, moment sum) into a scratch register first -- a v_mov_b64 per fma inside the
+// Nelder-Mead loop, ~20 % of an evaluation's instructions.  fnma_ = fma(-a, b, c), fmas_ = fma(a, b, -c).
+__device__ __forceinline__ double fma_(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double fnma_(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double fmas_(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // sin d and cos d - 1 for |d| <= 0.25 by their Taylor polynomials (truncation < 1e-18), as
 // explicit fused multiply-adds (our own arithmetic: not part of the reference's expression
 // tree that -ffp-contract=off protects).
 __device__ __forceinline__ void small_sincosm1(double d, double& s, double& cm1) {
     const double z = d * d;
-    double ps = __builtin_fma(z, -1.0 / 6227020800.0, 1.0 / 39916800.0);  // z^6/13!, z^5/11!
-    ps = __builtin_fma(z, ps, -1.0 / 362880.0);
-    ps = __builtin_fma(z, ps, 1.0 / 5040.0);
-    ps = __builtin_fma(z, ps, -1.0 / 120.0);
-    ps = __builtin_fma(z, ps, 1.0 / 6.0);
-    s = __builtin_fma(-(d * z), ps, d);                                     // d - d^3/6 + ...
-    double pc = __builtin_fma(z, 1.0 / 87178291200.0, -1.0 / 479001600.0);  // z^7/14!, z^6/12!
-    pc = __builtin_fma(z, pc, 1.0 / 3628800.0);
-    pc = __builtin_fma(z, pc, -1.0 / 40320.0);
-    pc = __builtin_fma(z, pc, 1.0 / 720.0);
-    pc = __builtin_fma(z, pc, -1.0 / 24.0);
-    pc = __builtin_fma(z, pc, 0.5);
+    double ps = fma_(z, -1.0 / 6227020800.0, 1.0 / 39916800.0);  // z^6/13!, z^5/11!
+    ps = fma_(z, ps, -1.0 / 362880.0);
+    ps = fma_(z, ps, 1.0 / 5040.0);
+    ps = fma_(z, ps, -1.0 / 120.0);
+    ps = fma_(z, ps, 1.0 / 6.0);
+    s = fnma_(d * z, ps, d);                                     // d - d^3/6 + ...
+    double pc = fma_(z, 1.0 / 87178291200.0, -1.0 / 479001600.0);  // z^7/14!, z^6/12!
+    pc = fma_(z, pc, 1.0 / 3628800.0);
+    pc = fma_(z, pc, -1.0 / 40320.0);
+    pc = fma_(z, pc, 1.0 / 720.0);
+    pc = fma_(z, pc, -1.0 / 24.0);
+    pc = fma_(z, pc, 0.5);
     cm1 = -(z * pc);                                                        // -d^2/2 + d^4/24 - ...
 }
 
@@ -206,19 +230,13 @@ __device__ __forceinline__ void finish_moments(const SolveCtx& c, PoseMoments& m
     m.Rr = m.Srxx + m.Sryy;
 }
 
-// The moment-form energy is the build's own arithmetic -- an exact regrouping of the reference's
-// per-beam sum, not its expression tree -- so it may use fused multiply-adds.  They are written
-// out (fma_) instead of left to `fp contract`: every kernel form (lane, quad, sequential,
-// fast and generic path) then rounds identically by construction.
-__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
-
 // Observation energy in moment form at (px, py) and heading th_o + d, given
 // al = cos d - 1 and be = sin d, and (anisotropic Q only) cos/sin of the heading.
 __device__ __forceinline__ double moments_energy(const SolveCtx& c, const PoseMoments& m, double px, double py,
                                                  double al, double be, double cth, double sth) {
     const double dx = px - m.pox, dy = py - m.poy;
     if (ICM_PROBE_FAST_TRIG_ONLY || c.Q0 == c.Q1) {   // (wave-uniform: the weights are kernel arguments; the probe counts this path)
-        const double g1 = fma_(al, m.Swx, fma_(-be, m.Swy, m.Srx));
+        const double g1 = fma_(al, m.Swx, fnma_(be, m.Swy, m.Srx));
         const double g2 = fma_(al, m.Swy, fma_(be, m.Swx, m.Sry));
         const double cross = fma_(dx, g1, fma_(dy, g2, fma_(al, m.AW, be * m.Bq)));
         const double rr = fma_(dx, dx, dy * dy);
@@ -261,7 +279,7 @@ __device__ __forceinline__ double pose_energy_moments_t(const SolveCtx& c, const
     double cth, sth, al, be;
     if (!GENERIC || fabs(dl) <= 0.25) {
         small_sincosm1(dl, be, al);
-        cth = m.co + fma_(m.co, al, -(m.so * be));
+        cth = m.co + fmas_(m.co, al, m.so * be);
         sth = m.so + fma_(m.so, al, m.co * be);
     } else {
         sth = sin(th);
@@ -280,7 +298,7 @@ __device__ __forceinline__ double pose_energy_moments_t(const SolveCtx& c, const
     const double nextR = fma_(s0 * c.R0, s0, fma_(s1 * c.R1, s1, (s2 * c.R2) * s2));
     const double ex = c.xpx - px, ey = c.xpy - py;
     const double p0 = c.o2x - fma_(cth, ex, sth * ey);
-    const double p1 = c.o2y - fma_(cth, ey, -(sth * ex));
+    const double p1 = c.o2y - fmas_(cth, ey, sth * ex);
     const double p2 = GENERIC ? wrap_pi(a3) : wrap_small(a3);
     const double nextO = c.cte * fma_(p0, p0, fma_(p1, p1, p2 * p2));
     return ((c.wn * (nextR + nextO) + prevR) + hh) + prevO;
@@ -385,8 +403,8 @@ struct Vtx {
 __device__ __forceinline__ double div3(double x) {
     const double z = 1.0 / 3.0;
     const double q = x * z;
-    const double r = __builtin_fma(-3.0, q, x);
-    return __builtin_fma(r, z, q);
+    const double r = fnma_(q, 3.0, x);
+    return fma_(r, z, q);
 }
 
 __device__ __forceinline__ void cswap(Vtx& a, Vtx& b) {

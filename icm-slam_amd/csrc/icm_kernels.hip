@@ -526,6 +526,45 @@ __global__ __launch_bounds__(kBlock) void k_associate_brute(const double* __rest
     }
 }
 
+// One scan against a reference map, on its own (Mapa.actualizar's association step,
+// scripts/ICM_SLAM_tools.py:169-172, outside a sweep): obs (n,2) row-major world points, the
+// first K columns of the reference map; the literal cdist / argmin (first index on ties) / gate.
+// One thread per observation, landmark table tiled through LDS.
+__global__ __launch_bounds__(kBlock) void k_scan_labels(const double* __restrict__ obs, int n,
+                                                        const double* __restrict__ mapx, const double* __restrict__ mapy,
+                                                        int K, double thr, int* __restrict__ label) {
+    constexpr int TILE = 1024;
+    __shared__ double sx[TILE], sy[TILE];
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const bool on = j < n;
+    double wx = 0.0, wy = 0.0;
+    if (on) {
+        wx = obs[2 * (size_t)j];
+        wy = obs[2 * (size_t)j + 1];
+    }
+    double best = __builtin_huge_val();
+    int bid = -1;
+    for (int k0 = 0; k0 < K; k0 += TILE) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < TILE && k0 + k < K; k += kBlock) {
+            sx[k] = mapx[k0 + k];
+            sy[k] = mapy[k0 + k];
+        }
+        __syncthreads();
+        const int kn = min(TILE, K - k0);
+        if (on)
+            for (int k = 0; k < kn; ++k) {
+                const double dx = sx[k] - wx, dy = sy[k] - wy;
+                const double d = sqrt(dx * dx + dy * dy);
+                if (d < best) {
+                    best = d;
+                    bid = k0 + k;
+                }
+            }
+    }
+    if (on) label[j] = (bid >= 0 && !(best > thr)) ? bid : -1;
+}
+
 // ---------------------------------------------------------------------------------------
 // Fused phase A: association + per-pose grouping.  For every distinct label of the scan
 // (label -1 = the scan's gated-out beams, which the reference folds into ONE new landmark,

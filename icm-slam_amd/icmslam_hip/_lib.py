@@ -58,6 +58,7 @@ SIGNATURES = {
     "icm_solve_one": (C.c_int, [_H, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp]),
     "icm_energy_one": (C.c_int, [_H, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp]),
     "icm_cluster_first_scan": (C.c_int, [_dp, C.c_int64, C.c_double, _ip]),
+    "icm_associate": (C.c_int, [_H, _dp, C.c_int64, _dp, C.c_int64, _dp, _dp, _lp, _lp]),
     "icm_init_pass": (C.c_int, [_H, _dp, _dp, _dp, _lp, _dp]),
     "icm_filtrar": (C.c_int, [C.POINTER(IcmConfig), _dp, _dp, C.c_int64, _dp, _dp, _lp]),
     "icm_enable_timing": (C.c_int, [_H, C.c_int]),

@@ -74,6 +74,32 @@ def cluster_first_scan(points, t):
 
 
 _PREFILTER_ENGINES = {}
+_SCAN_ENGINES = {}
+
+
+def actualizar_scan(config, mapa, mapa_referencia, obs, lact, cant_obs_i, device=0):
+    """Mapa.actualizar for one scan through the C-ABI (`icm_associate`, reference
+    scripts/ICM_SLAM_tools.py:128-201): `mapa` (2,L) float64 C-contiguous and `cant_obs_i` (L) are
+    updated IN PLACE, `mapa_referencia` (2,K) is only read.  Returns (labels c (n,) int64, new
+    landmarks_actuales)."""
+    key = (id(config), device)
+    eng = _SCAN_ENGINES.get(key)
+    if eng is None:
+        eng = _SCAN_ENGINES[key] = SweepEngine(config, device)
+    L = int(config.L)
+    if not (isinstance(mapa, np.ndarray) and mapa.dtype == np.float64 and mapa.flags.c_contiguous and mapa.shape == (2, L)):
+        raise ValueError("actualizar: mapa must be a C-contiguous float64 (2,L) array (it is updated in place)")
+    if not (isinstance(cant_obs_i, np.ndarray) and cant_obs_i.dtype == np.float64 and cant_obs_i.flags.c_contiguous and cant_obs_i.shape == (L,)):
+        raise ValueError("actualizar: cant_obs_i must be a C-contiguous float64 (L,) array")
+    o = _f64(obs)
+    if o.ndim != 2 or (o.shape[0] and o.shape[1] != 2):
+        raise ValueError("actualizar: obs must be (n,2) world points")
+    n = o.shape[0]
+    ref = _f64(mapa_referencia) if int(lact) > 0 else np.zeros((2, 0))
+    c = np.zeros(max(n, 1), dtype=np.int64)
+    la = C.c_int64(int(lact))
+    eng._chk(eng.lib.icm_associate(eng.h, dptr(o), n, dptr(ref), ref.shape[1], dptr(mapa), dptr(cant_obs_i), C.byref(la), lptr(c)))
+    return c[:n], int(la.value)
 
 
 def prefilter_scans(config, scans, device=0):

@@ -243,6 +243,20 @@ int icm_get_entry_path(const icm_handle *h);
  * routine icm_filtrar.  Same results. */
 int icm_set_gpu_filtrar(icm_handle *h, int on);
 
+/* Mapa.actualizar for ONE scan, outside a sweep (reference scripts/ICM_SLAM_tools.py:128-201; the
+ * call the reference's online initialisation makes per sample, scripts/ICM_ROS.py:114):
+ *   obs (n,2) row-major world points of the scan's kept beams; map_ref (2,K_ref) row-major, NOT
+ *   modified; map (2,L) row-major running map and counts (L) = cant_obs_i, both updated in place;
+ *   *lact_inout = landmarks_actuales in and out; labels_out (n) = the reference's `c`.
+ * landmarks_actuales == 0: the first-scan branch (:160-165) -- single-linkage clusters at
+ * dist_thr, cluster centres and sizes.  Otherwise (:167-197): nearest column of
+ * map_ref[:, :landmarks_actuales] per observation on the GPU (cdist / argmin, first index on ties),
+ * gate at dist_thr, ONE fresh label for all gated-out observations of the scan, then
+ * the running-mean recurrence per label.  ICM_ERR_INDEX where the reference raises IndexError
+ * (label >= L), ICM_ERR_ARG for an empty reference map. */
+int icm_associate(icm_handle *h, const double *obs, int64_t n, const double *map_ref, int64_t K_ref,
+                  double *map, double *counts, int64_t *lact_inout, int64_t *labels_out);
+
 /* ---- instrumentation -------------------------------------------------------------------- */
 /* When enabled, every kernel launch of a sweep is bracketed by HIP events on the handle's
  * stream; icm_kernel_time() returns accumulated ms and launch count per kernel name. */

@@ -167,3 +167,74 @@ def test_message_stream_drives_the_same_pipeline():
     assert np.abs(ma - mb).max() <= 1e-9          # (yaw went through a quaternion: 1e-15 differences)
     dd = np.abs(xa - xb).max(axis=0)
     assert dd.max() <= 5e-3 and (dd > 1e-9).sum() <= 3
+
+
+def test_mapa_actualizar_replays_sweep_one_scan_by_scan():
+    """`Mapa.actualizar` as a public method (reference scripts/ICM_SLAM_tools.py:128-201, called per
+    sample by the online initialisation, scripts/ICM_ROS.py:114): replaying sweep 1 of the reference
+    scan by scan -- filtrar_z rows, tras_rot_z with the previous-sweep pose, actualizar against
+    mapa_viejo -- reproduces the reference's labels (exact) and gathered targets y[:, c] of every
+    pose, and the raw map / counters it hands to Mapa.filtrar."""
+    from ICM_SLAM_tools import ConfigICM, Mapa, tras_rot_z
+    cfg = ConfigICM("config_default.yaml")
+    init, pp, fz = gold("init_pass.npz"), gold("sweep1_perpose.npz"), gold("filtrar_z.npz")
+    d = gold("data_IJAC2018.npz")
+    x0 = d["odometry"][:, 0]
+    m = Mapa(cfg)
+    m.landmarks_actuales = int(init["landmarks_actuales"])
+    m.clear_obs()
+    y = np.zeros((2, cfg.L))
+    rows, off = fz["rows"], fz["offsets"]
+    where = {int(t): i for i, t in enumerate(pp["t"])}
+    worst = 0.0
+    for t in range(d["odometry"].shape[1]):
+        z = rows[off[t]:off[t + 1]].copy()
+        if z.shape[0] == 0:
+            continue
+        zt = tras_rot_z(x0 if t == 0 else init["x_init"][:, t], z)
+        y_id = id(y)
+        y, c = m.actualizar(y, init["map_init"], zt[:, 2:4])
+        assert id(y) == y_id and c.shape == (z.shape[0],)
+        if t in where:
+            i = where[t]
+            sl = slice(pp["offsets"][i], pp["offsets"][i + 1])
+            assert np.array_equal(c, pp["labels"][sl]), "labels of pose %d" % t
+            worst = max(worst, np.abs(y[:, c].T - pp["targets"][sl]).max())
+    print("actualizar replay: max|dtarget| %.2e over %d scans" % (worst, len(where)))
+    assert worst <= 1e-9
+    la = int(pp["filtrar_lact_in"])
+    assert m.landmarks_actuales == la
+    assert np.array_equal(m.cant_obs_i[:la], pp["filtrar_cnt_in"])
+    assert np.abs(y[:, :la] - pp["filtrar_y_in"]).max() <= 1e-9
+
+
+def test_mapa_actualizar_first_scan_branch_and_errors():
+    """landmarks_actuales == 0: the scan is clustered (single linkage at dist_thr) into the first
+    landmarks -- the reference's labels for scan 0 of the dataset; then the error behaviour."""
+    from ICM_SLAM_tools import ConfigICM, Mapa, tras_rot_z
+    cfg = ConfigICM("config_default.yaml")
+    init, fz, d = gold("init_pass.npz"), gold("filtrar_z.npz"), gold("data_IJAC2018.npz")
+    z = fz["rows"][fz["offsets"][0]:fz["offsets"][1]].copy()
+    zt = tras_rot_z(d["odometry"][:, 0], z)
+    m = Mapa(cfg)
+    y = np.zeros((2, cfg.L))
+    y, c = m.actualizar(y, y, zt[:, 2:4])
+    assert np.array_equal(c, init["labels_scan0"])
+    ncl = int(c.max()) + 1
+    assert m.landmarks_actuales == ncl
+    for i in range(ncl):
+        assert np.array_equal(y[:, i], np.mean(zt[c == i, 2:4], axis=0))
+        assert m.cant_obs_i[i] == (c == i).sum()
+    # a scan far from every landmark: ONE new landmark for all of its beams (SURVEY Appendix B.1)
+    far = zt[:, 2:4] + 500.0
+    y, c2 = m.actualizar(y, y.copy(), far)
+    assert (c2 == ncl).all() and m.landmarks_actuales == ncl + 1 and m.cant_obs_i[ncl] == far.shape[0]
+    assert np.abs(y[:, ncl] - far.sum(axis=0) / far.shape[0]).max() <= 1e-12
+    # no room for a new landmark: IndexError like the reference (scripts/ICM_SLAM_tools.py:191)
+    small = ConfigICM(D=dict(N=2, deltat=0.1, L=ncl + 1, Q=[1, 1], R=[1, 1, 1], cte_odom=1.0, cota=300, dist_thr=1.0,
+                             dist_thr_obs=1, rango_laser_max=10.0, radio=0.137))
+    m3 = Mapa(small)
+    m3.landmarks_actuales = ncl + 1
+    y3 = np.zeros((2, ncl + 1))
+    with pytest.raises(IndexError):
+        m3.actualizar(y3, y[:, :ncl + 1].copy(), far + 500.0)
