@@ -32,7 +32,7 @@ enum KernelId {
 };
 const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_scan", "k_associate_brute", "k_assoc_group", "k_compact",
                                        "radix_sort_pairs", "k_lm_bounds", "k_lm_scan_totals", "k_stats_prefix",
-                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_solve_deferred", "k_filtrar_grid", "k_neigh_table",
+                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_solve_deferred", "k_filtrar", "k_neigh_table",
                                        "k_chunk_l1", "k_chunk_l2", "k_lm_l3", "k_rec_push"};
 
 template <class T>
@@ -84,8 +84,11 @@ struct icm_handle {
 
     // association grid
     Grid grid;
-    DevBuf<int> g_cell, fl_cid, fl_cell_cnt, fl_cell_fill, fl_info;
-    DevBuf<LmRec> g_lm, fl_tbl;
+    DevBuf<int> g_cell, fl_cid, fl_cell_cnt, fl_cell_fill, fl_info, fl_nn, fl_lab, fl_comp, fl_csize, fl_isl, fl_rank, fl_scan_tot;
+    DevBuf<FlState> fl_state;
+    DevBuf<double> fl_nd;
+    DevBuf<LmRec> g_lm;
+    int filtrar_path = 0;   // last sweep: 0 GPU without merges, 1 GPU with merges, 2 host routine
     DevBuf<GridParams> gpar;
     DevBuf<NeighRec> g_nb;   // per-cell 3x3 neighbourhood records (k_neigh_table)
     int max_cells = 0;
@@ -260,7 +263,9 @@ int icm_destroy(icm_handle* h) {
     DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->label, &h->bloc, &h->st_label, &h->st_k,
                          &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags, &h->scan_tot};
     for (auto* b : di) b->release();
-    h->g_lm.release(); h->fl_tbl.release(); h->gpar.release(); h->g_nb.release();
+    h->g_lm.release(); h->gpar.release(); h->g_nb.release();
+    h->fl_nn.release(); h->fl_lab.release(); h->fl_comp.release(); h->fl_csize.release(); h->fl_isl.release(); h->fl_rank.release();
+    h->fl_scan_tot.release(); h->fl_state.release(); h->fl_nd.release();
     h->fl_cid.release(); h->fl_cell_cnt.release(); h->fl_cell_fill.release(); h->fl_info.release();
     h->fl_px.release(); h->fl_py.release(); h->fl_pc.release(); h->counts_new.release();
     h->e_b.release(); h->e_wr.release(); h->tgt.release(); h->e_w.release();
@@ -319,6 +324,25 @@ int icm_upload(icm_handle* h, const double* ranges, const double* odo, const dou
     return ICM_OK;
 }
 
+// Buffers of the landmark table, its search grid and Mapa.filtrar (sized by L alone).
+static int reserve_map_buffers(icm_handle* h) {
+    const size_t L = (size_t)h->cfg.L;
+    h->max_cells = (int)(8 * L + 4096);   // bound of both grid builders (build_grid on the host, k_fl_* on the device)
+    const size_t nc = (size_t)h->max_cells + 2;
+    HIPCHK(h, h->y_raw.reserve(2 * L)); HIPCHK(h, h->cnt_raw.reserve(L));
+    HIPCHK(h, h->g_lm.reserve(L)); HIPCHK(h, h->gpar.reserve(1));
+    HIPCHK(h, h->fl_nn.reserve(L)); HIPCHK(h, h->fl_lab.reserve(L)); HIPCHK(h, h->fl_comp.reserve(kCompStride * L)); HIPCHK(h, h->fl_csize.reserve(L));
+    HIPCHK(h, h->fl_isl.reserve(L + 1)); HIPCHK(h, h->fl_rank.reserve(L + 2)); HIPCHK(h, h->fl_nd.reserve(L)); HIPCHK(h, h->fl_state.reserve(1));
+    HIPCHK(h, h->fl_scan_tot.reserve(2 * (nc / kScanTile + 2)));
+    HIPCHK(h, h->fl_cid.reserve(L)); HIPCHK(h, h->fl_cell_cnt.reserve(nc)); HIPCHK(h, h->fl_cell_fill.reserve(nc));
+    HIPCHK(h, h->fl_info.reserve(8)); HIPCHK(h, h->fl_px.reserve(L)); HIPCHK(h, h->fl_py.reserve(L)); HIPCHK(h, h->fl_pc.reserve(L));
+    HIPCHK(h, h->counts_new.reserve(L));
+    HIPCHK(h, h->mapx.reserve(L)); HIPCHK(h, h->mapy.reserve(L));
+    HIPCHK(h, h->g_cell.reserve(nc));
+    HIPCHK(h, h->g_nb.reserve((size_t)h->max_cells));
+    return ICM_OK;
+}
+
 int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     if (!h) return ICM_ERR_ARG;
     if (!h->uploaded) FAIL(h, ICM_ERR_ARG, "icm_prefilter: call icm_upload first");
@@ -359,13 +383,11 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     const size_t L = (size_t)h->cfg.L;
     HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(8));
     HIPCHK(h, h->stats_own.reserve(3 * L + 8)); HIPCHK(h, h->off_sx.reserve(L)); HIPCHK(h, h->off_sy.reserve(L));
-    HIPCHK(h, h->off_n.reserve(L)); HIPCHK(h, h->y_raw.reserve(2 * L)); HIPCHK(h, h->cnt_raw.reserve(L));
-    HIPCHK(h, h->g_lm.reserve(L)); HIPCHK(h, h->fl_tbl.reserve(L)); HIPCHK(h, h->gpar.reserve(1));
-    HIPCHK(h, h->fl_cid.reserve(L)); HIPCHK(h, h->fl_cell_cnt.reserve(8 * L + 4096 + 2)); HIPCHK(h, h->fl_cell_fill.reserve(8 * L + 4096 + 2));
-    HIPCHK(h, h->fl_info.reserve(8)); HIPCHK(h, h->fl_px.reserve(L)); HIPCHK(h, h->fl_py.reserve(L)); HIPCHK(h, h->fl_pc.reserve(L));
-    HIPCHK(h, h->counts_new.reserve(L));
-    HIPCHK(h, h->mapx.reserve(L)); HIPCHK(h, h->mapy.reserve(L));
-    HIPCHK(h, h->g_cell.reserve(8 * L + 4096 + 2));
+    HIPCHK(h, h->off_n.reserve(L));
+    {
+        int rcm = reserve_map_buffers(h);
+        if (rcm) return rcm;
+    }
     // poses per chunk: a chunk is one wave's serial work, so short sequences take short chunks
     h->chunk_poses = nloc >= 65536 ? 64 : (nloc >= 16384 ? 32 : 16);
     h->nchunks = (nloc + h->chunk_poses - 1) / h->chunk_poses;
@@ -377,8 +399,6 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         HIPCHK(h, h->ms.reserve(3 * (size_t)h->nsuper * L));
         h->ms_clean = false;
     }
-    h->max_cells = (int)(8 * L + 4096);   // bound of both grid builders (build_grid, block_build_grid)
-    HIPCHK(h, h->g_nb.reserve((size_t)h->max_cells));
     size_t tmp_bytes = 0;
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, nz, 0, 32, h->stream));
     HIPCHK(h, h->sort_tmp.reserve(tmp_bytes + 256));
@@ -568,6 +588,69 @@ __global__ void k_halo_from_headers(double* __restrict__ x, const double* __rest
     }
 }
 
+static FiltrarArgs filtrar_args(icm_handle* h) {
+    const int L = (int)h->cfg.L;
+    FiltrarArgs fa;
+    fa.y_raw = h->y_raw.p; fa.cnt_raw = h->cnt_raw.p; fa.stats_all = h->world > 1 ? h->stats_all : nullptr;
+    fa.n_new_dev = h->new_rank.p + h->nloc;   // (total of the new-landmark scan, single rank)
+    fa.L = L; fa.lact0 = h->lact0; fa.world = h->world; fa.stride = (int)icm_stats_stride(h);
+    fa.cota = h->cfg.cota; fa.thr = h->cfg.dist_thr; fa.max_cells = h->max_cells;
+    fa.st = h->fl_state.p; fa.px = h->fl_px.p; fa.py = h->fl_py.p; fa.pc = h->fl_pc.p; fa.nd = h->fl_nd.p;
+    fa.cid = h->fl_cid.p; fa.cell_cnt = h->fl_cell_cnt.p; fa.cell_fill = h->fl_cell_fill.p; fa.nn = h->fl_nn.p;
+    fa.lab = h->fl_lab.p; fa.comp = h->fl_comp.p; fa.csize = h->fl_csize.p; fa.isl = h->fl_isl.p; fa.rank = h->fl_rank.p;
+    fa.mapx = h->mapx.p; fa.mapy = h->mapy.p; fa.counts_new = h->counts_new.p;
+    fa.gpar = h->gpar.p; fa.g_cell = h->g_cell.p; fa.g_lm = h->g_lm.p; fa.info = h->fl_info.p;
+    return fa;
+}
+
+// counting-sort grid over the n points (x, y) into the search structures (g_cell, g_lm); the
+// grid parameters are in fl_state.gp and the cell counters are zero (k_fl_scatter / k_fl_setup)
+static void launch_grid_chain(icm_handle* h, hipStream_t fs, const FiltrarArgs& fa, const double* x, const double* y, const int* n_dev) {
+    const int L = (int)h->cfg.L, nall = h->max_cells + 1, ntiles = (nall + kScanTile - 1) / kScanTile;
+    TIMED(h, KID_FILTRAR, (k_fl_cell_count<<<nblocks_threads(L), kBlock, 0, fs>>>(fa, x, y, n_dev)));
+    // one scan, two copies: cell starts and the fill cursors
+    TIMED(h, KID_FILTRAR, (k_scan_tiles<<<ntiles, kBlock, 0, fs>>>(h->fl_cell_cnt.p, h->fl_cell_cnt.p, h->g_cell.p, h->fl_cell_fill.p, h->fl_scan_tot.p, nall)));
+    TIMED(h, KID_FILTRAR, (k_scan_fix<<<ntiles, kBlock, 0, fs>>>(h->g_cell.p, h->fl_cell_fill.p, h->fl_scan_tot.p, nall, ntiles)));
+    TIMED(h, KID_FILTRAR, (k_fl_fill<<<nblocks_threads(L), kBlock, 0, fs>>>(fa, x, y, n_dev)));
+}
+
+// Mapa.filtrar + the search grid of the refined map, queued on `fs` (no host involvement).
+static int launch_filtrar(icm_handle* h, hipStream_t fs) {
+    const int L = (int)h->cfg.L;
+    const FiltrarArgs fa = filtrar_args(h);
+    const int nb = std::min(kFlMaxBlocks, (L + kFB - 1) / kFB);
+    const int chunk = ((L + nb - 1) / nb + kFB - 1) / kFB * kFB;
+    TIMED(h, KID_FILTRAR, (k_fl_count<<<nb, kFB, 0, fs>>>(fa, chunk)));
+    TIMED(h, KID_FILTRAR, (k_fl_scatter<<<nb, kFB, 0, fs>>>(fa, chunk)));
+    launch_grid_chain(h, fs, fa, h->fl_px.p, h->fl_py.p, &h->fl_state.p->n);
+    TIMED(h, KID_FILTRAR, (k_fl_pairs<<<nblocks_threads(L), kBlock, 0, fs>>>(fa)));
+    TIMED(h, KID_FILTRAR, (k_fl_finalize<<<nb, kFB, 0, fs>>>(fa)));
+    // the grid's size is only known on the device: one thread per cell of the capacity
+    TIMED(h, KID_NEIGH, (k_neigh_table<<<nblocks_threads(h->max_cells), kBlock, 0, fs>>>(GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, nullptr}, h->g_nb.p, h->max_cells)));
+    HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
+// Survivors closer than dist_thr: label propagation, renumbering and count-weighted means on the
+// device, then the grid over the refined map.  n = survivors (host copy of info[0]).
+static int launch_filtrar_merge(icm_handle* h, hipStream_t fs, int n) {
+    const int L = (int)h->cfg.L;
+    const FiltrarArgs fa = filtrar_args(h);
+    const int nb = std::min(kFlMaxBlocks, (L + kFB - 1) / kFB);
+    TIMED(h, KID_FILTRAR, (k_fl_components<<<nblocks_threads(L), kBlock, 0, fs>>>(fa)));
+    TIMED(h, KID_FILTRAR, (k_fl_label_flags<<<nblocks_threads(L), kBlock, 0, fs>>>(fa)));
+    TIMED(h, KID_FILTRAR, (k_exscan_i32<<<1, 1024, 0, fs>>>(h->fl_isl.p, h->fl_rank.p, n)));
+    TIMED(h, KID_FILTRAR, (k_fl_gather<<<nblocks_threads(L), kBlock, 0, fs>>>(fa)));
+    const int* n_ref = &h->fl_state.p->n_ref;
+    TIMED(h, KID_FILTRAR, (k_fl_extent<<<nb, kFB, 0, fs>>>(fa, h->mapx.p, h->mapy.p, n_ref)));
+    TIMED(h, KID_FILTRAR, (k_fl_setup<<<nb, kFB, 0, fs>>>(fa, n_ref)));
+    launch_grid_chain(h, fs, fa, h->mapx.p, h->mapy.p, n_ref);
+    TIMED(h, KID_FILTRAR, (k_fl_finalize_merged<<<1, 1, 0, fs>>>(fa)));
+    TIMED(h, KID_NEIGH, (k_neigh_table<<<nblocks_threads(h->max_cells), kBlock, 0, fs>>>(GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, nullptr}, h->g_nb.p, h->max_cells)));
+    HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
 // Phase A + local statistics.
 int icm_sweep_local(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
@@ -736,25 +819,13 @@ int icm_sweep_targets(icm_handle* h) {
         for (int r = 0; r < h->world && r < 64; ++r)
             HIPCHK(h, hipMemcpyAsync(h->pin_d + 3 * Ls + 16 + r, h->stats_all + (size_t)r * (size_t)icm_stats_stride(h) + 3 * Ls, sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
     if (h->gpu_filtrar) {
-        FiltrarArgs fa;
-        fa.y_raw = h->y_raw.p; fa.cnt_raw = h->cnt_raw.p; fa.stats_all = h->world > 1 ? h->stats_all : nullptr;
-        fa.L = L; fa.lact0 = h->lact0; fa.n_new_loc = (int)h->n_new_loc; fa.world = h->world; fa.stride = (int)icm_stats_stride(h);
-        fa.cota = h->cfg.cota; fa.thr = h->cfg.dist_thr; fa.max_cells = 8 * L + 4096;
-        fa.px = h->fl_px.p; fa.py = h->fl_py.p; fa.pc = h->fl_pc.p; fa.cid = h->fl_cid.p;
-        fa.cell_cnt = h->fl_cell_cnt.p; fa.cell_fill = h->fl_cell_fill.p; fa.tbl = h->fl_tbl.p;
-        fa.mapx = h->mapx.p; fa.mapy = h->mapy.p; fa.counts_new = h->counts_new.p;
-        fa.gpar = h->gpar.p; fa.g_cell = h->g_cell.p; fa.g_lm = h->g_lm.p; fa.info = h->fl_info.p;
-        if (h->timing) {  // serialised on the main stream so that the events bracket it
-            TIMED(h, KID_FILTRAR, (k_filtrar_grid<<<1, kFB, 0, h->stream>>>(fa)));
-            TIMED(h, KID_NEIGH, (k_neigh_table<<<nblocks_threads(h->max_cells), kBlock, 0, h->stream>>>(GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, nullptr}, h->g_nb.p, h->max_cells)));
+        hipStream_t fs = h->timing ? h->stream : h->copy_stream;   // (timing: serialised on the main stream so that the events bracket it)
+        int rc = launch_filtrar(h, fs);
+        if (rc) return rc;
+        if (h->timing) {
             HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
-        } else {
-            k_filtrar_grid<<<1, kFB, 0, h->copy_stream>>>(fa);
-            // the grid's size is only known on the device: one thread per cell of the capacity
-            k_neigh_table<<<nblocks_threads(h->max_cells), kBlock, 0, h->copy_stream>>>(GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, nullptr}, h->g_nb.p, h->max_cells);
         }
-        HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
     }
     if (h->path_used == 1) {  // next sweep's matrix: cleared here, under the solves (icm_sweep_finish waits for this stream)
@@ -862,6 +933,17 @@ int icm_sweep_finish(icm_handle* h) {
     if (h->lact_raw > (int64_t)L) FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L");
     h->h_yraw.assign(h->pin_d, h->pin_d + 2 * L);
     h->h_cntraw.assign(h->pin_d + 2 * L, h->pin_d + 3 * L);
+    h->filtrar_path = 2;
+    if (h->gpu_filtrar && h->pin_i[9] == 1) {
+        // survivors closer than dist_thr: merged on the device (rare; one extra round trip)
+        int rc = launch_filtrar_merge(h, h->copy_stream, h->pin_i[8]);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+        if (h->pin_i[9] == 0) h->filtrar_path = 1;
+    } else if (h->gpu_filtrar && h->pin_i[9] == 0) {
+        h->filtrar_path = 0;
+    }
     if (h->gpu_filtrar && h->pin_i[9] == 0) {
         // Mapa.filtrar and the search grid of the refined map were produced on the GPU
         // (k_filtrar_grid); the refined map becomes the next mapa_viejo (scripts/ICM_ROS.py:311)
@@ -1105,6 +1187,61 @@ int icm_filtrar(const icm_config* cfg, const double* y, const double* counts, in
     return filtrar_host(*cfg, y, counts, lact, y_out, counts_out, lact_out, g_create_err);
 }
 
+static int launch_filtrar(icm_handle* h, hipStream_t fs);
+static int launch_filtrar_merge(icm_handle* h, hipStream_t fs, int n);
+
+int icm_filtrar_device(icm_handle* h, const double* y, const double* counts, int64_t lact, double* y_out,
+                       double* counts_out, int64_t* lact_out, int* path_out) {
+    if (!h) return ICM_ERR_ARG;
+    if (!y || !counts || !y_out || !counts_out || !lact_out) FAIL(h, ICM_ERR_ARG, "icm_filtrar_device: null argument");
+    const size_t L = (size_t)h->cfg.L;
+    if (lact < 0 || lact > (int64_t)L) FAIL(h, ICM_ERR_ARG, "icm_filtrar_device: landmarks_actuales outside [0, L]");
+    if (h->world > 1) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_filtrar_device: not on a handle bound to a multi-rank exchange");
+    HIPCHK(h, hipSetDevice(h->device));
+    {
+        int rc = reserve_map_buffers(h);
+        if (rc) return rc;
+    }
+    HIPCHK(h, h->new_rank.reserve((size_t)h->nloc + 1));
+    hipStream_t st = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->y_raw.p, y, 2 * L * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->cnt_raw.p, counts, L * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemsetAsync(h->new_rank.p + h->nloc, 0, sizeof(int), st));
+    const int lact0_keep = h->lact0;
+    h->lact0 = (int)lact;
+    int rc = launch_filtrar(h, st);
+    int info[4] = {0, 2, 0, 0};
+    if (!rc) {
+        HIPCHK(h, hipMemcpyAsync(info, h->fl_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (info[1] == 1) {
+            rc = launch_filtrar_merge(h, st, info[0]);
+            if (!rc) {
+                HIPCHK(h, hipMemcpyAsync(info, h->fl_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
+                HIPCHK(h, hipStreamSynchronize(st));
+                if (info[1] == 0) info[1] = -1;   // merged on the device
+            }
+        }
+    }
+    h->lact0 = lact0_keep;
+    h->have_state = false;   // the search structures now belong to this map, not to the sweep state
+    if (rc) return rc;
+    if (info[1] == 2) {      // coincident landmarks / empty map / a component beyond kCompMax: exact host routine
+        if (path_out) *path_out = 2;
+        return filtrar_host(h->cfg, y, counts, lact, y_out, counts_out, lact_out, h->err);
+    }
+    const size_t n = (size_t)info[0];
+    std::fill(y_out, y_out + 2 * L, 0.0);
+    if (n) {
+        HIPCHK(h, hipMemcpy(y_out, h->mapx.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(y_out + L, h->mapy.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(h, hipMemcpy(counts_out, h->counts_new.p, L * sizeof(double), hipMemcpyDeviceToHost));
+    *lact_out = (int64_t)n;
+    if (path_out) *path_out = info[1] == -1 ? 1 : 0;
+    return ICM_OK;
+}
+
 int icm_cluster_first_scan(const double* pts, int64_t n, double t, int32_t* labels_out) {
     if (!pts || !labels_out) {
         g_create_err = "icm_cluster_first_scan: null argument";
@@ -1341,6 +1478,14 @@ int icm_set_entry_path(icm_handle* h, int mode) {
 }
 
 int icm_get_entry_path(const icm_handle* h) { return h ? h->path_used : ICM_ERR_ARG; }
+
+int icm_last_filtrar_info(const icm_handle* h, int64_t* out3) {
+    if (!h || !out3) return ICM_ERR_ARG;
+    out3[0] = h->lact;
+    out3[1] = h->filtrar_path;
+    out3[2] = h->filtrar_path == 2 ? -1 : h->pin_i[10];
+    return ICM_OK;
+}
 
 int icm_set_gpu_filtrar(icm_handle* h, int on) {
     if (!h) return ICM_ERR_ARG;

@@ -1365,31 +1365,55 @@ __global__ __launch_bounds__(kBlock) void k_rec_push(int nrec, int G, int L, con
 
 // ---------------------------------------------------------------------------------------
 // Phase D on the GPU: Mapa.filtrar (reference scripts/ICM_SLAM_tools.py:204-265) and the search
-// grid of the refined map, fused in ONE single-workgroup kernel (the map is a few thousand
-// landmarks: every step is a handful of items per thread, the cost is launch latency, so one
-// launch on a side stream, concurrent with the pose solves).
-//   1. prune landmarks seen < cota times (order preserving compaction)
-//   2. uniform grid (cell >= dist_thr) over the survivors, nearest other landmark of each
-//   3. no pair closer than dist_thr (the usual case): the refined map is the survivors, each
-//      as the reference's count-weighted mean of one term, (y*n)/n; build its search grid.
-//      Otherwise (merges, or coincident landmarks whose zero distance the reference replaces
-//      by the global maximum) set info[1] and leave the exact sequential label propagation
-//      (:246-253) to the host routine.
-// info: [0] survivors = new landmarks_actuales, [1] needs the host path, [2] pairs to merge.
+// grid of the refined map, on a side stream under the pose solves.  A chain of small
+// multi-workgroup kernels (the map is ~1e4 landmarks: every step is one or two items per thread;
+// a single workgroup spent 0.16 ms here on dependent-load latency alone):
+//   k_fl_count     per block of the landmark range: survivors (seen >= cota times) and their extent
+//   k_fl_scatter   order-preserving compaction of the survivors; grid parameters; cell counters := 0
+//   k_fl_cell_count / k_scan_tiles+fix / k_fl_fill   counting-sort grid (cell >= dist_thr), written
+//                  straight into the search structures of the next sweep
+//   k_fl_pairs     nearest other survivor of each survivor (3x3 cells): close / coincident counts
+//   k_fl_finalize  no pair closer than dist_thr (the usual case): the refined map is the
+//                  survivors, each as the reference's count-weighted mean of one term, (y*n)/n
+// Pairs closer than dist_thr (info[1] = 1) are merged on the device too (host-triggered, rare):
+//   k_fl_components  every component of the nearest-neighbour graph (<= kCompMax members) replays
+//                    the reference's sequential label propagation (:246-249) on its own members
+//   k_fl_label_flags / k_exscan_i32 / k_fl_gather   gap-closing renumbering (:251-253), count-weighted
+//                    means (:256-260); then the grid chain again over the refined map.
+// Coincident survivors (whose zero distance the reference replaces by the global maximum), an empty
+// map and components larger than kCompMax (numpy's pairwise summation kicks in at 8 terms) set
+// info[1] = 2: the exact host routine takes over.
+// info: [0] landmarks_actuales after the filter, [1] 0 done / 1 merge pending / 2 host, [2] close pairs.
 // ---------------------------------------------------------------------------------------
-constexpr int kFB = 1024;  // threads of the fused kernel
+constexpr int kFB = 1024;          // threads per block of the filter kernels
+constexpr int kFlMaxBlocks = 64;   // blocks of the order-preserving prune
+constexpr int kCompMax = 7;        // largest component merged on the device
+constexpr int kCompStride = 8;
+
+struct FlState {
+    int n;         // survivors of the prune
+    int close;     // survivors with another survivor closer than dist_thr
+    int same;      // survivors coincident with another one
+    int host;      // the host routine must take over
+    int n_ref;     // landmarks after merging
+    int pad[3];
+    GridParams gp;
+    int part_keep[kFlMaxBlocks];
+    double part_mm[4 * kFlMaxBlocks];   // per block: min x, max x, min y, max y of its points
+};
 
 struct FiltrarArgs {
     const double* y_raw;    // (2,L)
     const double* cnt_raw;  // (L)
     const double* stats_all;  // sharded: per-rank headers hold the new-landmark counts
-    int L, lact0, n_new_loc, world, stride;
+    const int* n_new_dev;     // single rank: landmarks created this sweep (device word)
+    int L, lact0, world, stride;
     double cota, thr;
     int max_cells;
     // scratch
-    double *px, *py, *pc;
-    int *cid, *cell_cnt, *cell_fill;
-    LmRec* tbl;
+    FlState* st;
+    double *px, *py, *pc, *nd;
+    int *cid, *cell_cnt, *cell_fill, *nn, *lab, *comp, *csize, *isl, *rank;
     // outputs
     double *mapx, *mapy, *counts_new;
     GridParams* gpar;
@@ -1420,37 +1444,47 @@ __device__ __forceinline__ int block_exscan_1024(int v, int* wsum, int& total) {
     return pre + inc - v;
 }
 
-// Grid over n points: parameters, cell-sorted record table (order inside a cell is arbitrary;
-// every consumer breaks ties on the landmark id explicitly).  `cell_min` = smallest cell edge.
-__device__ void block_build_grid(const double* __restrict__ x, const double* __restrict__ y, int n, double cell_min,
-                                 int max_cells, int* __restrict__ cid, int* __restrict__ cell_start,
-                                 int* __restrict__ cell_fill, LmRec* __restrict__ tbl, GridParams* __restrict__ gp_out,
-                                 double* red, int* wsum) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    double x0 = __builtin_huge_val(), x1 = -__builtin_huge_val(), y0 = x0, y1 = x1;
-    for (int i = tid; i < n; i += kFB) {
-        x0 = fmin(x0, x[i]); x1 = fmax(x1, x[i]);
-        y0 = fmin(y0, y[i]); y1 = fmax(y1, y[i]);
+__device__ __forceinline__ int fl_lact(const FiltrarArgs& a) {   // landmarks in use before the filter
+    int lact = a.lact0;
+    if (a.world > 1) {
+        for (int r = 0; r < a.world; ++r) lact += (int)a.stats_all[(size_t)r * a.stride + 3 * (size_t)a.L];
+    } else {
+        lact += *a.n_new_dev;
+    }
+    return min(lact, a.L);
+}
+
+// min / max of (x, y) over the block -> part_mm[4 b ..]
+__device__ __forceinline__ void fl_block_extent(double x0, double x1, double y0, double y1, double* red, double* out4) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        x0 = fmin(x0, __shfl_xor(x0, d, kWave));
+        x1 = fmax(x1, __shfl_xor(x1, d, kWave));
+        y0 = fmin(y0, __shfl_xor(y0, d, kWave));
+        y1 = fmax(y1, __shfl_xor(y1, d, kWave));
     }
     __syncthreads();
-    red[tid] = x0; red[kFB + tid] = x1; red[2 * kFB + tid] = y0; red[3 * kFB + tid] = y1;
+    if (lane == 0) {
+        red[4 * w] = x0; red[4 * w + 1] = x1; red[4 * w + 2] = y0; red[4 * w + 3] = y1;
+    }
     __syncthreads();
-    for (int d = kFB / 2; d > 0; d >>= 1) {
-        if (tid < d) {
-            red[tid] = fmin(red[tid], red[tid + d]);
-            red[kFB + tid] = fmax(red[kFB + tid], red[kFB + tid + d]);
-            red[2 * kFB + tid] = fmin(red[2 * kFB + tid], red[2 * kFB + tid + d]);
-            red[3 * kFB + tid] = fmax(red[3 * kFB + tid], red[3 * kFB + tid + d]);
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < kFB / kWave; ++q) {
+            x0 = fmin(x0, red[4 * q]); x1 = fmax(x1, red[4 * q + 1]);
+            y0 = fmin(y0, red[4 * q + 2]); y1 = fmax(y1, red[4 * q + 3]);
         }
-        __syncthreads();
+        out4[0] = x0; out4[1] = x1; out4[2] = y0; out4[3] = y1;
     }
-    x0 = red[0]; x1 = red[kFB]; y0 = red[2 * kFB]; y1 = red[3 * kFB];
-    __syncthreads();
+}
+
+// Grid over n points of the given extent: cell edge >= cell_min, at most max_cells cells.
+__device__ __forceinline__ GridParams fl_grid_params(double x0, double x1, double y0, double y1, int n, double cell_min, int max_cells) {
     double cell = cell_min > 0.0 ? cell_min : 1.0;
     int nx = 1, ny = 1;
     if (n > 0) {
         // (bounded: with a non-finite coordinate in the map the extent never fits; everything
-        // then lands in one cell instead of the workgroup spinning)
+        // then lands in one cell instead of the kernel spinning)
         for (int tries = 0; tries < 128; ++tries) {
             const double nxd = floor((x1 - x0) / cell) + 1.0, nyd = floor((y1 - y0) / cell) + 1.0;
             if (nxd * nyd <= (double)max_cells) {
@@ -1467,130 +1501,153 @@ __device__ void block_build_grid(const double* __restrict__ x, const double* __r
     } else {
         x0 = y0 = 0.0;
     }
-    const double inv = 1.0 / cell;
-    const int ncell = nx * ny, nall = ncell + 1;
-    for (int c = tid; c < nall; c += kFB) cell_start[c] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += kFB) {
-        const int c = grid_cell(y[i], y0, inv, ny) * nx + grid_cell(x[i], x0, inv, nx);
-        cid[i] = c;
-        atomicAdd(&cell_start[c], 1);
-    }
-    __syncthreads();
-    // Exclusive scan of the cell counts.  Each of the 16 waves owns a contiguous segment of
-    // cells and sweeps it in coalesced 64-cell steps with an in-register wave scan and a
-    // running carry (no barrier inside); a second coalesced pass adds the segment offsets.
-    {
-        const int seg = ((nall + kFB / kWave - 1) / (kFB / kWave) + kWave - 1) / kWave * kWave;  // multiple of 64
-        const int lo = min(w * seg, nall), hi = min(lo + seg, nall);
-        int carry = 0;
-        for (int base = lo; base < hi; base += kWave) {
-            const int c = base + lane;
-            const int v = c < hi ? cell_start[c] : 0;
-            int inc = v;
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                const int u = __shfl_up(inc, d, kWave);
-                if (lane >= d) inc += u;
-            }
-            if (c < hi) cell_start[c] = carry + inc - v;
-            carry += __shfl(inc, kWave - 1, kWave);
-        }
-        if (lane == 0) wsum[w] = carry;
-        __syncthreads();
-        int off = 0;
-        for (int q = 0; q < w; ++q) off += wsum[q];
-        for (int base = lo; base < hi; base += kWave) {
-            const int c = base + lane;
-            if (c < hi) {
-                const int v = cell_start[c] + off;
-                cell_start[c] = v;
-                cell_fill[c] = v;
-            }
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += kFB) {
-        const int p = atomicAdd(&cell_fill[cid[i]], 1);
-        tbl[p] = LmRec{x[i], y[i], i, 0, 0, 0};
-    }
-    if (tid == 0) *gp_out = GridParams{x0, y0, inv, nx, ny};
-    __syncthreads();
+    return GridParams{x0, y0, 1.0 / cell, nx, ny};
 }
 
-__global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
-    __shared__ double red[4 * kFB];
-    __shared__ int wsum[kFB / kWave];
-    __shared__ int s_cnt[2];
-    __shared__ GridParams s_gp;
-    const int tid = threadIdx.x;
-    // landmarks in use before the filter: lact0 + the new ones of all ranks
-    int lact = a.lact0 + a.n_new_loc;
-    if (a.world > 1) {
-        lact = a.lact0;
-        for (int r = 0; r < a.world; ++r) lact += (int)a.stats_all[(size_t)r * a.stride + 3 * (size_t)a.L];
+// Extent of all points from the per-block partials, grid parameters, cell counters := 0.
+__device__ __forceinline__ void fl_grid_setup(const FiltrarArgs& a, int nb, int n) {
+    double x0 = __builtin_huge_val(), x1 = -__builtin_huge_val(), y0 = x0, y1 = x1;
+    for (int q = 0; q < nb; ++q) {
+        x0 = fmin(x0, a.st->part_mm[4 * q]); x1 = fmax(x1, a.st->part_mm[4 * q + 1]);
+        y0 = fmin(y0, a.st->part_mm[4 * q + 2]); y1 = fmax(y1, a.st->part_mm[4 * q + 3]);
     }
-    lact = min(lact, a.L);
-    // 1. prune, keeping the order
-    int n = 0;
-    for (int base = 0; base < lact; base += kFB) {
-        const int i = base + tid;
-        const int keep = (i < lact && a.cnt_raw[i] >= a.cota) ? 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.st->gp = fl_grid_params(x0, x1, y0, y1, n, a.thr * (1.0 + 1e-9), a.max_cells);
+    for (int c = blockIdx.x * kFB + threadIdx.x; c <= a.max_cells; c += gridDim.x * kFB) a.cell_cnt[c] = 0;
+}
+
+__global__ __launch_bounds__(kFB) void k_fl_count(FiltrarArgs a, int chunk) {
+    __shared__ double red[4 * (kFB / kWave)];
+    __shared__ int wsum[kFB / kWave];
+    const int lact = fl_lact(a), b = blockIdx.x;
+    const int lo = min(b * chunk, lact), hi = min(lo + chunk, lact);
+    int keep = 0;
+    double x0 = __builtin_huge_val(), x1 = -__builtin_huge_val(), y0 = x0, y1 = x1;
+    for (int i = lo + threadIdx.x; i < hi; i += kFB)
+        if (a.cnt_raw[i] >= a.cota) {
+            ++keep;
+            const double x = a.y_raw[i], y = a.y_raw[a.L + i];
+            x0 = fmin(x0, x); x1 = fmax(x1, x);
+            y0 = fmin(y0, y); y1 = fmax(y1, y);
+        }
+    int tot;
+    (void)block_exscan_1024(keep, wsum, tot);
+    fl_block_extent(x0, x1, y0, y1, red, a.st->part_mm + 4 * b);
+    if (threadIdx.x == 0) {
+        a.st->part_keep[b] = tot;
+        if (b == 0) a.st->close = a.st->same = a.st->host = 0;
+    }
+}
+
+__global__ __launch_bounds__(kFB) void k_fl_scatter(FiltrarArgs a, int chunk) {
+    __shared__ int wsum[kFB / kWave];
+    const int lact = fl_lact(a), b = blockIdx.x, nb = gridDim.x;
+    int off = 0, n = 0;
+    for (int q = 0; q < nb; ++q) {
+        const int v = a.st->part_keep[q];
+        if (q < b) off += v;
+        n += v;
+    }
+    const int lo = min(b * chunk, lact), hi = min(lo + chunk, lact);
+    for (int base = lo; base < hi; base += kFB) {   // keeps the order (block-uniform trip count)
+        const int i = base + threadIdx.x;
+        const int keep = (i < hi && a.cnt_raw[i] >= a.cota) ? 1 : 0;
         int tot;
-        const int pos = n + block_exscan_1024(keep, wsum, tot);
+        const int pos = off + block_exscan_1024(keep, wsum, tot);
         if (keep) {
             a.px[pos] = a.y_raw[i];
             a.py[pos] = a.y_raw[a.L + i];
             a.pc[pos] = a.cnt_raw[i];
         }
-        n += tot;
+        off += tot;
         __syncthreads();
     }
-    if (tid == 0) {
-        s_cnt[0] = 0;
-        s_cnt[1] = 0;
+    if (b == 0 && threadIdx.x == 0) a.st->n = n;
+    fl_grid_setup(a, nb, n);
+}
+
+// extent of n points (the refined map after merging) -> per-block partials
+__global__ __launch_bounds__(kFB) void k_fl_extent(FiltrarArgs a, const double* __restrict__ x, const double* __restrict__ y,
+                                                   const int* __restrict__ n_dev) {
+    __shared__ double red[4 * (kFB / kWave)];
+    const int n = *n_dev;
+    double x0 = __builtin_huge_val(), x1 = -__builtin_huge_val(), y0 = x0, y1 = x1;
+    for (int i = blockIdx.x * kFB + threadIdx.x; i < n; i += gridDim.x * kFB) {
+        x0 = fmin(x0, x[i]); x1 = fmax(x1, x[i]);
+        y0 = fmin(y0, y[i]); y1 = fmax(y1, y[i]);
     }
-    __syncthreads();
-    // 2. ONE fine grid (cell >= dist_thr) over the survivors, written straight into the search
-    //    structures of the next sweep, and the pair check on it: is any other survivor closer
-    //    than dist_thr, or coincident?
-    int merges = 0, coincident = 0;
-    if (n > 0) {
-        block_build_grid(a.px, a.py, n, a.thr * (1.0 + 1e-9), a.max_cells, a.cid, a.g_cell, a.cell_fill, a.g_lm, &s_gp, red, wsum);
-        const GridParams gp = s_gp;
-        for (int i = tid; i < n; i += kFB) {
-            const double xi = a.px[i], yi = a.py[i];
-            const int cx = grid_cell(xi, gp.gx0, gp.inv, gp.nx), cy = grid_cell(yi, gp.gy0, gp.inv, gp.ny);
-            const int c0 = max(cx - 1, 0), c1 = min(cx + 1, gp.nx - 1);
-            bool close = false, same = false;
-            for (int ry = max(cy - 1, 0); ry <= min(cy + 1, gp.ny - 1); ++ry)
-                for (int p = a.g_cell[ry * gp.nx + c0]; p < a.g_cell[ry * gp.nx + c1 + 1]; ++p) {
-                    const LmRec c = a.g_lm[p];
-                    if (c.id == i) continue;
-                    const double dx = xi - c.x, dy = yi - c.y;
-                    const double d = sqrt(dx * dx + dy * dy);
-                    same |= d == 0.0;
-                    close |= d < a.thr;
-                }
-            if (close) atomicAdd(&s_cnt[0], 1);
-            if (same) atomicAdd(&s_cnt[1], 1);
+    fl_block_extent(x0, x1, y0, y1, red, a.st->part_mm + 4 * blockIdx.x);
+}
+__global__ __launch_bounds__(kFB) void k_fl_setup(FiltrarArgs a, const int* __restrict__ n_dev) { fl_grid_setup(a, gridDim.x, *n_dev); }
+
+__global__ __launch_bounds__(kBlock) void k_fl_cell_count(FiltrarArgs a, const double* __restrict__ x, const double* __restrict__ y,
+                                                          const int* __restrict__ n_dev) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= *n_dev) return;
+    const GridParams gp = a.st->gp;
+    const int c = grid_cell(y[i], gp.gy0, gp.inv, gp.ny) * gp.nx + grid_cell(x[i], gp.gx0, gp.inv, gp.nx);
+    a.cid[i] = c;
+    atomicAdd(&a.cell_cnt[c], 1);
+}
+
+// order inside a cell is arbitrary: every consumer breaks ties on the landmark id explicitly
+__global__ __launch_bounds__(kBlock) void k_fl_fill(FiltrarArgs a, const double* __restrict__ x, const double* __restrict__ y,
+                                                    const int* __restrict__ n_dev) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= *n_dev) return;
+    const int p = atomicAdd(&a.cell_fill[a.cid[i]], 1);
+    a.g_lm[p] = LmRec{x[i], y[i], i, 0, 0, 0};
+}
+
+// nearest other survivor (smallest index on ties, like np.argmin over the column)
+__global__ __launch_bounds__(kBlock) void k_fl_pairs(FiltrarArgs a) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.st->n) return;
+    const GridParams gp = a.st->gp;
+    const double xi = a.px[i], yi = a.py[i];
+    const int cx = grid_cell(xi, gp.gx0, gp.inv, gp.nx), cy = grid_cell(yi, gp.gy0, gp.inv, gp.ny);
+    const int c0 = max(cx - 1, 0), c1 = min(cx + 1, gp.nx - 1);
+    double best = __builtin_huge_val();
+    int bid = -1;
+    bool same = false;
+    for (int ry = max(cy - 1, 0); ry <= min(cy + 1, gp.ny - 1); ++ry)
+        for (int p = a.g_cell[ry * gp.nx + c0]; p < a.g_cell[ry * gp.nx + c1 + 1]; ++p) {
+            const LmRec c = a.g_lm[p];
+            if (c.id == i) continue;
+            const double dx = xi - c.x, dy = yi - c.y;
+            const double d = sqrt(dx * dx + dy * dy);
+            same |= d == 0.0;
+            if (d < best || (d == best && c.id < bid)) {
+                best = d;
+                bid = c.id;
+            }
         }
-        __syncthreads();
-        merges = s_cnt[0];
-        coincident = s_cnt[1];
-    }
-    const bool host = n == 0 || merges > 0 || coincident > 0;
-    if (tid == 0) {
+    a.nn[i] = bid;
+    a.nd[i] = best;
+    if (best < a.thr) atomicAdd(&a.st->close, 1);
+    if (same) atomicAdd(&a.st->same, 1);
+}
+
+__global__ __launch_bounds__(kFB) void k_fl_finalize(FiltrarArgs a) {
+    const int n = a.st->n;
+    const bool host = n == 0 || a.st->same > 0;
+    const bool merge = a.st->close > 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.info[0] = n;
-        a.info[1] = host ? 1 : 0;
-        a.info[2] = merges;
+        a.info[1] = host ? 2 : (merge ? 1 : 0);
+        a.info[2] = a.st->close;
     }
-    if (host) return;  // (the search structures hold the raw survivors: the host path re-uploads them)
-    // 3. refined map = survivors; the count-weighted mean of a single term is (y*n)/n (:258-260).
-    //    The grid cells were assigned from the raw coordinates, which differ from the refined
-    //    ones by an ulp at most -- far inside the 1e-9 slack of the cell edge over dist_thr --
-    //    so only the table's coordinates are rewritten.
-    for (int i = tid; i < a.L; i += kFB) {
+    if (host || merge) {
+        // the search structures hold the raw survivors (a consistent grid: k_neigh_table, queued behind,
+        // must never read stale parameters); the merge chain / the host path rebuild them
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.gpar = a.st->gp;
+        return;
+    }
+    // refined map = survivors; the count-weighted mean of a single term is (y*n)/n (:258-260).
+    // The grid cells were assigned from the raw coordinates, which differ from the refined
+    // ones by an ulp at most -- far inside the 1e-9 slack of the cell edge over dist_thr --
+    // so only the table's coordinates are rewritten.
+    const int stride = gridDim.x * kFB, t0 = blockIdx.x * kFB + threadIdx.x;
+    for (int i = t0; i < a.L; i += stride) {
         if (i < n) {
             const double c = a.pc[i];
             a.mapx[i] = (a.px[i] * c) / c;
@@ -1600,13 +1657,123 @@ __global__ __launch_bounds__(kFB) void k_filtrar_grid(FiltrarArgs a) {
             a.counts_new[i] = 0.0;
         }
     }
-    __syncthreads();
-    for (int p = tid; p < n; p += kFB) {
+    for (int p = t0; p < n; p += stride) {
         const int id = a.g_lm[p].id;
-        a.g_lm[p].x = a.mapx[id];
-        a.g_lm[p].y = a.mapy[id];
+        const double c = a.pc[id];
+        a.g_lm[p].x = (a.px[id] * c) / c;
+        a.g_lm[p].y = (a.py[id] * c) / c;
     }
-    if (tid == 0) *a.gpar = s_gp;
+    if (t0 == 0) *a.gpar = a.st->gp;
+}
+
+// ---- merging (rare) ----
+// One thread per survivor.  A survivor with a neighbour closer than dist_thr collects its component
+// of the nearest-neighbour graph (edges i -> nn[i], followed both ways; the members are within
+// dist_thr of each other along the chain, so the reverse edges are found in the 3x3 cells around a
+// member).  The smallest member replays the reference's loop over its component:
+//   for i in close (ascending): c[c == c[b[i]]] = c[i]          (scripts/ICM_SLAM_tools.py:246-249)
+// -- components never interact, so the global sequential loop factorises over them.
+__global__ __launch_bounds__(kBlock) void k_fl_components(FiltrarArgs a) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int n = a.st->n;
+    if (i >= n) return;
+    if (!(a.nd[i] < a.thr)) {   // nobody close: its own landmark
+        a.lab[i] = i;
+        a.csize[i] = 1;
+        a.comp[(size_t)i * kCompStride] = i;
+        return;
+    }
+    const GridParams gp = a.st->gp;
+    int mem[kCompMax + 1];
+    int cnt = 1;
+    mem[0] = i;
+    bool over = false;
+    for (int k = 0; k < cnt && !over; ++k) {
+        const int u = mem[k];
+        auto add = [&](int v) {
+            for (int q = 0; q < cnt; ++q)
+                if (mem[q] == v) return;
+            if (cnt > kCompMax - 1) {
+                over = true;
+                return;
+            }
+            mem[cnt++] = v;
+        };
+        add(a.nn[u]);
+        const double xu = a.px[u], yu = a.py[u];
+        const int cx = grid_cell(xu, gp.gx0, gp.inv, gp.nx), cy = grid_cell(yu, gp.gy0, gp.inv, gp.ny);
+        const int c0 = max(cx - 1, 0), c1 = min(cx + 1, gp.nx - 1);
+        for (int ry = max(cy - 1, 0); ry <= min(cy + 1, gp.ny - 1) && !over; ++ry)
+            for (int p = a.g_cell[ry * gp.nx + c0]; p < a.g_cell[ry * gp.nx + c1 + 1] && !over; ++p) {
+                const int v = a.g_lm[p].id;
+                if (v != u && a.nd[v] < a.thr && a.nn[v] == u) add(v);
+            }
+    }
+    if (over) {
+        a.st->host = 1;
+        return;
+    }
+    for (int k = 1; k < cnt; ++k) {   // ascending
+        const int v = mem[k];
+        int q = k - 1;
+        while (q >= 0 && mem[q] > v) {
+            mem[q + 1] = mem[q];
+            --q;
+        }
+        mem[q + 1] = v;
+    }
+    if (mem[0] != i) return;   // the smallest member leads
+    int c[kCompMax + 1];
+    for (int k = 0; k < cnt; ++k) c[k] = mem[k];
+    for (int k = 0; k < cnt; ++k) {
+        int kb = 0;
+        for (int q = 0; q < cnt; ++q)
+            if (mem[q] == a.nn[mem[k]]) kb = q;
+        const int from = c[kb], to = c[k];
+        if (from != to)
+            for (int q = 0; q < cnt; ++q)
+                if (c[q] == from) c[q] = to;
+    }
+    const int l = c[0];
+    for (int k = 0; k < cnt; ++k) {
+        a.lab[mem[k]] = l;
+        a.csize[mem[k]] = 0;
+        a.comp[(size_t)l * kCompStride + k] = mem[k];
+    }
+    a.csize[l] = cnt;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fl_label_flags(FiltrarArgs a) {   // isl[l] = label l survives
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < a.st->n) a.isl[i] = a.csize[i] > 0 ? 1 : 0;
+}
+
+// renumbered, count-weighted means (:251-260); rank = exclusive scan of isl
+__global__ __launch_bounds__(kBlock) void k_fl_gather(FiltrarArgs a) {
+    const int l = blockIdx.x * kBlock + threadIdx.x;
+    const int n = a.st->n;
+    const int n_ref = a.rank[n];
+    if (l == 0) a.st->n_ref = n_ref;
+    if (l < a.L && l >= n_ref) a.counts_new[l] = 0.0;
+    if (l >= n || a.csize[l] == 0) return;
+    const int r = a.rank[l], k = a.csize[l];
+    double cs = 0.0, sx = 0.0, sy = 0.0;
+    for (int q = 0; q < k; ++q) {   // members in ascending order, like the boolean mask
+        const int m = a.comp[(size_t)l * kCompStride + q];
+        const double c = a.pc[m];
+        cs += c;
+        sx += a.px[m] * c;
+        sy += a.py[m] * c;
+    }
+    a.mapx[r] = sx / cs;
+    a.mapy[r] = sy / cs;
+    a.counts_new[r] = cs;
+}
+
+__global__ void k_fl_finalize_merged(FiltrarArgs a) {
+    a.info[0] = a.st->n_ref;
+    a.info[1] = a.st->host ? 2 : 0;
+    *a.gpar = a.st->gp;
 }
 
 // Target per kept beam: y[:, c] of scripts/ICM_ROS.py:152 (parity tests, per-beam energy).

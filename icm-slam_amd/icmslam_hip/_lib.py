@@ -70,6 +70,8 @@ SIGNATURES = {
     "icm_set_debug": (C.c_int, [_H, C.c_int]),
     "icm_get_solve_diag": (C.c_int, [_H, _dp]),
     "icm_set_gpu_filtrar": (C.c_int, [_H, C.c_int]),
+    "icm_last_filtrar_info": (C.c_int, [_H, _lp]),
+    "icm_filtrar_device": (C.c_int, [_H, _dp, _dp, C.c_int64, _dp, _dp, _lp, C.POINTER(C.c_int)]),
     "icm_set_solve_lanes": (C.c_int, [_H, C.c_int]),
     "icm_snapshot_state": (C.c_int, [_H]),
     "icm_restore_state": (C.c_int, [_H]),

@@ -403,6 +403,23 @@ class SweepEngine:
     def set_gpu_filtrar(self, on):
         self._chk(self.lib.icm_set_gpu_filtrar(self.h, int(bool(on))))
 
+    def last_filtrar_info(self):
+        """(landmarks after the last sweep's Mapa.filtrar, where it ran: 0 GPU / 1 GPU with merges /
+        2 host routine, landmarks that had a neighbour closer than dist_thr)."""
+        a = np.zeros(3, dtype=np.int64)
+        self._chk(self.lib.icm_last_filtrar_info(self.h, lptr(a)))
+        return int(a[0]), int(a[1]), int(a[2])
+
+    def filtrar_device(self, y, counts, lact):
+        """Mapa.filtrar on the GPU for a caller-held (2,L) map -> (y_out (2,L), counts_out (L), lact, path)."""
+        y, counts = _f64(y), _f64(counts)
+        if y.shape != (2, self.L) or counts.shape != (self.L,):
+            raise ValueError("filtrar: map must be (2,L) and counts (L,)")
+        yo, co = np.zeros((2, self.L)), np.zeros(self.L)
+        lo, path = C.c_int64(0), C.c_int(0)
+        self._chk(self.lib.icm_filtrar_device(self.h, dptr(y), dptr(counts), int(lact), dptr(yo), dptr(co), C.byref(lo), C.byref(path)))
+        return yo, co, int(lo.value), int(path.value)
+
     def set_brute_force(self, on):
         self._chk(self.lib.icm_set_brute_force(self.h, int(bool(on))))
 

@@ -238,10 +238,21 @@ int icm_get_fused_deferred(icm_handle *h, int64_t *waves);
 int icm_set_entry_path(icm_handle *h, int mode);
 int icm_get_entry_path(const icm_handle *h);
 
-/* Where Mapa.filtrar runs inside a sweep: 1 (default) = fused GPU kernel `k_filtrar_grid`
- * (falls back to the host routine when landmarks have to be merged), 0 = always the host
- * routine icm_filtrar.  Same results. */
+/* Where Mapa.filtrar runs inside a sweep: 1 (default) = on the GPU (the k_fl_* kernel chain on a
+ * side stream: prune, grid, nearest-neighbour pairs, and -- when survivors are closer than dist_thr
+ * -- label propagation, renumbering and count-weighted means; only coincident landmarks, an empty
+ * map or a merge component of more than 7 landmarks go to the host routine), 0 = always the host
+ * routine icm_filtrar.  Same results.
+ * icm_last_filtrar_info: [0] landmarks_actuales after the last sweep's filter, [1] where it ran
+ * (0 GPU, no merges; 1 GPU with merges; 2 host routine), [2] landmarks that had a neighbour closer
+ * than dist_thr (-1 on the host path). */
 int icm_set_gpu_filtrar(icm_handle *h, int on);
+int icm_last_filtrar_info(const icm_handle *h, int64_t *out3);
+/* Mapa.filtrar (scripts/ICM_SLAM_tools.py:204-265) on the GPU for a caller-held map: same
+ * arguments as icm_filtrar; *path_out as [1] above.  Invalidates the handle's sweep state
+ * (icm_set_state again before the next sweep). */
+int icm_filtrar_device(icm_handle *h, const double *y, const double *counts, int64_t lact, double *y_out,
+                       double *counts_out, int64_t *lact_out, int *path_out);
 
 /* Mapa.actualizar for ONE scan, outside a sweep (reference scripts/ICM_SLAM_tools.py:128-201; the
  * call the reference's online initialisation makes per sample, scripts/ICM_ROS.py:114):
