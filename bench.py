@@ -191,6 +191,8 @@ class Job:
         else:
             from icmslam_hip import SweepEngine
             self.eng = eng = SweepEngine(cfg, local_rank)
+            if args.pipeline:
+                eng.set_pipeline(True)
             eng.upload(wl.scans, wl.odometry, wl.u, t_begin=self.t_begin, t_end=self.t_end, pose_major=True)
         self.t_upload = time.perf_counter() - t0
         if sharded:
@@ -419,6 +421,7 @@ def run_rank(args):
                    "landmarks": K, "beams": B, "kept_beams": st["kept_beams"] if world == 1 else None,
                    "parallelism": "pose-shard x%d" % world,
                    "entry_pipeline": job.eng.entry_path() if hasattr(job.eng, "entry_path") else None,
+                   "segments_pipelined": bool(job.eng.pipeline_used()) if hasattr(job.eng, "pipeline_used") else None,
                    "state_rewind": ("initial state restored on the device every %d sweeps" % RESET_EVERY) if job.rewind
                    else "none: %d consecutive sweeps from the initial state" % (args.steps + args.warmup),
                    "collectives_per_sweep": 0 if not sharded else "1 all-gather of [3L+8] f64 statistics + 1 halo all-gather of 48 B per rank"},
@@ -472,6 +475,7 @@ def main():
     ap.add_argument("--cpu-poses", type=int, default=-1, help="prefix length of the CPU baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the drop-in and config-3 records")
+    ap.add_argument("--pipeline", action="store_true", help="two time segments pipelined over two streams (icm_set_pipeline(h, 1)): A/B comparison")
     ap.add_argument("--no-rewind", action="store_true", help="never rewind the state, however many sweeps")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="N > 1: strong = the workload's sequence split N ways (BASELINE configs[4], the headline); "

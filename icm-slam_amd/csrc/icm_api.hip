@@ -125,8 +125,8 @@ struct icm_handle {
     int solve_flag_waves = 0;
     int solve_epoch = 0;
     int fused_spin_limit = 1 << 17;   // polls (x ~0.2 us) an even wave waits for its odd neighbours before deferring
-    bool ms_clean = false;   // the [superchunk x L] matrix is zero (cleared on the side stream under the solves)
     int fuse_colours = 1;    // 1: both colours of an unsharded red-black sweep in one launch (k_solve_m_fused)
+    bool ms_clean = false;   // the [superchunk x L] matrix is zero (cleared on the side stream under the solves)
     int entry_path = -1;     // -1 automatic, 0 sort-based pipeline, 1 hierarchical (falls back when a table overflows)
     bool hier_ok = true;     // cleared by an overflow until the next icm_set_state
     int path_used = 0;       // pipeline of the last sweep: 0 sort-based, 1 hierarchical
@@ -151,6 +151,17 @@ struct icm_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // raw-map download overlapped with the solves
     hipStream_t copy_stream = nullptr;
+    // Pipelined sweeps (unsharded red-black, hierarchical entry pipeline): the sequence is cut at an
+    // even pose into two time segments; the solves of one segment run on solve_stream beside phase
+    // A/B of the other on the main stream.
+    hipStream_t solve_stream = nullptr;
+    hipEvent_t ev_m[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};   // moments ready / solves done, per segment
+    bool solves_in_flight = false;   // ev_s[] are recorded and the main stream has not joined them yet
+    int pipeline = 0;                // icm_set_pipeline (off by default: measured slower than one stream)
+    bool pipe_ok = true;             // cleared by a table overflow until the next icm_set_state
+    int pipe_used = 0;               // the last sweep ran pipelined
+    DevBuf<double> x_bak, l3_carry;
+    DevBuf<int> scan_carry;
     hipEvent_t ev_map = nullptr, ev_copied = nullptr;
     bool map_copy_pending = false;
 };
@@ -198,6 +209,14 @@ int icm_valu_per_eval(void) { return ICM_VALU_PER_EVAL; }
 
 const char* icm_last_error(const icm_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+// The solve stream gets the highest priority: its few, register-hungry workgroups must win a slot
+// whenever one opens beside the phase A/B grids of the main stream.
+static hipError_t create_solve_stream(hipStream_t* s) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // (hi = greatest priority, numerically lowest)
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+}
+
 int icm_create(const icm_config* cfg, int device, icm_handle** out) {
     if (!cfg || !out) {
         g_create_err = "icm_create: null argument";
@@ -225,6 +244,9 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = create_solve_stream(&h->solve_stream)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->ev_m[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&h->ev_m[1], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->ev_s[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&h->ev_s[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->ev_map, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_i), 64 * sizeof(int), hipHostMallocMapped)) != hipSuccess ||
@@ -255,6 +277,8 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
 int icm_destroy(icm_handle* h) {
     if (!h) return ICM_OK;
     (void)hipSetDevice(h->device);
+    if (h->solve_stream) (void)hipStreamSynchronize(h->solve_stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     (void)hipStreamSynchronize(h->stream);
     DevBuf<double>* dd[] = {&h->ranges, &h->cosb, &h->sinb, &h->odo, &h->u, &h->bd, &h->bx, &h->by, &h->x_own, &h->x0,
                             &h->mapx, &h->mapy, &h->st_sx, &h->st_sy, &h->pose_m, &h->pose_c, &h->pose_s2, &h->btx, &h->bty, &h->stats_own, &h->off_sx, &h->off_sy, &h->off_n, &h->y_raw,
@@ -282,6 +306,9 @@ int icm_destroy(icm_handle* h) {
     if (h->ev_map) (void)hipEventDestroy(h->ev_map);
     if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->solve_stream) { (void)hipStreamSynchronize(h->solve_stream); (void)hipStreamDestroy(h->solve_stream); }
+    for (int q = 0; q < 2; ++q) { if (h->ev_m[q]) (void)hipEventDestroy(h->ev_m[q]); if (h->ev_s[q]) (void)hipEventDestroy(h->ev_s[q]); }
+    h->x_bak.release(); h->l3_carry.release(); h->scan_carry.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ICM_OK;
@@ -290,10 +317,22 @@ int icm_destroy(icm_handle* h) {
 int icm_set_stream(icm_handle* h, void* s) {
     if (!h) return ICM_ERR_ARG;
     (void)hipSetDevice(h->device);
+    if (h->solve_stream) (void)hipStreamSynchronize(h->solve_stream);
+    h->solves_in_flight = false;
     (void)hipStreamSynchronize(h->stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = reinterpret_cast<hipStream_t>(s);
     h->own_stream = false;
+    return ICM_OK;
+}
+
+// The solves of a pipelined sweep run on solve_stream.  Everything else in this library orders
+// itself on the main stream, so any entry point that reads or replaces the poses first makes the
+// main stream wait for them (the next pipelined sweep waits per segment instead).
+static int join_solves(icm_handle* h) {
+    if (!h->solves_in_flight) return ICM_OK;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_s[1], 0));   // (ev_s[0] precedes it on the same stream)
+    h->solves_in_flight = false;
     return ICM_OK;
 }
 
@@ -304,6 +343,7 @@ int icm_upload(icm_handle* h, const double* ranges, const double* odo, const dou
     if (T < 2 || B < 1 || t_begin < 0 || t_end > T || t_begin >= t_end) FAIL(h, ICM_ERR_ARG, "icm_upload: bad T/B/shard");
     if (T > (1 << 30) || B > 8192 || (t_end - t_begin) * B > (int64_t)2000000000) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_upload: sequence too large for 32-bit beam indices");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     h->T = T; h->B = B; h->t_begin = t_begin; h->nloc = t_end - t_begin;
     const size_t nr = (size_t)h->nloc * (size_t)B;
     HIPCHK(h, h->ranges.reserve(nr));
@@ -397,7 +437,6 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         const size_t nrec = (size_t)h->nchunks * kT1;
         HIPCHK(h, h->rec_label.reserve(nrec)); HIPCHK(h, h->rec_s.reserve(3 * nrec)); HIPCHK(h, h->rec_off.reserve(3 * nrec));
         HIPCHK(h, h->ms.reserve(3 * (size_t)h->nsuper * L));
-        h->ms_clean = false;
     }
     size_t tmp_bytes = 0;
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, nz, 0, 32, h->stream));
@@ -461,6 +500,7 @@ int icm_set_state(icm_handle* h, const double* x, const double* x0, const double
     if (lact_in < K) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_set_state: landmarks_actuales < columns of mapa_viejo is not supported");
     if (lact_in > h->cfg.L) FAIL(h, ICM_ERR_INDEX, "icm_set_state: landmarks_actuales > L");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     const size_t T = (size_t)h->T;
     if (!h->x_external) {  // (re)size with the sequence: a handle may be re-used for a longer one
         HIPCHK(h, h->x_own.reserve(3 * T));
@@ -483,6 +523,7 @@ int icm_set_state(icm_handle* h, const double* x, const double* x0, const double
     if (rc) return rc;
     h->have_state = true;
     h->hier_ok = true;
+    h->pipe_ok = true;
     return ICM_OK;
 }
 
@@ -593,6 +634,7 @@ static FiltrarArgs filtrar_args(icm_handle* h) {
     FiltrarArgs fa;
     fa.y_raw = h->y_raw.p; fa.cnt_raw = h->cnt_raw.p; fa.stats_all = h->world > 1 ? h->stats_all : nullptr;
     fa.n_new_dev = h->new_rank.p + h->nloc;   // (total of the new-landmark scan, single rank)
+    fa.sweep_flags = nullptr;
     fa.L = L; fa.lact0 = h->lact0; fa.world = h->world; fa.stride = (int)icm_stats_stride(h);
     fa.cota = h->cfg.cota; fa.thr = h->cfg.dist_thr; fa.max_cells = h->max_cells;
     fa.st = h->fl_state.p; fa.px = h->fl_px.p; fa.py = h->fl_py.p; fa.pc = h->fl_pc.p; fa.nd = h->fl_nd.p;
@@ -607,17 +649,19 @@ static FiltrarArgs filtrar_args(icm_handle* h) {
 // grid parameters are in fl_state.gp and the cell counters are zero (k_fl_scatter / k_fl_setup)
 static void launch_grid_chain(icm_handle* h, hipStream_t fs, const FiltrarArgs& fa, const double* x, const double* y, const int* n_dev) {
     const int L = (int)h->cfg.L, nall = h->max_cells + 1, ntiles = (nall + kScanTile - 1) / kScanTile;
+    const int* ab = &h->fl_state.p->abort;
     TIMED(h, KID_FILTRAR, (k_fl_cell_count<<<nblocks_threads(L), kBlock, 0, fs>>>(fa, x, y, n_dev)));
     // one scan, two copies: cell starts and the fill cursors
-    TIMED(h, KID_FILTRAR, (k_scan_tiles<<<ntiles, kBlock, 0, fs>>>(h->fl_cell_cnt.p, h->fl_cell_cnt.p, h->g_cell.p, h->fl_cell_fill.p, h->fl_scan_tot.p, nall)));
-    TIMED(h, KID_FILTRAR, (k_scan_fix<<<ntiles, kBlock, 0, fs>>>(h->g_cell.p, h->fl_cell_fill.p, h->fl_scan_tot.p, nall, ntiles)));
+    TIMED(h, KID_FILTRAR, (k_scan_tiles<<<ntiles, kBlock, 0, fs>>>(h->fl_cell_cnt.p, h->fl_cell_cnt.p, h->g_cell.p, h->fl_cell_fill.p, h->fl_scan_tot.p, nall, ab)));
+    TIMED(h, KID_FILTRAR, (k_scan_fix<<<ntiles, kBlock, 0, fs>>>(h->g_cell.p, h->fl_cell_fill.p, h->fl_scan_tot.p, nall, ntiles, nullptr, nullptr, ab)));
     TIMED(h, KID_FILTRAR, (k_fl_fill<<<nblocks_threads(L), kBlock, 0, fs>>>(fa, x, y, n_dev)));
 }
 
 // Mapa.filtrar + the search grid of the refined map, queued on `fs` (no host involvement).
-static int launch_filtrar(icm_handle* h, hipStream_t fs) {
+static int launch_filtrar(icm_handle* h, hipStream_t fs, bool guarded = false) {
     const int L = (int)h->cfg.L;
-    const FiltrarArgs fa = filtrar_args(h);
+    FiltrarArgs fa = filtrar_args(h);
+    if (guarded) fa.sweep_flags = h->flags.p;   // queued without a host look at the sweep's flags: the kernels look themselves
     const int nb = std::min(kFlMaxBlocks, (L + kFB - 1) / kFB);
     const int chunk = ((L + nb - 1) / nb + kFB - 1) / kFB * kFB;
     TIMED(h, KID_FILTRAR, (k_fl_count<<<nb, kFB, 0, fs>>>(fa, chunk)));
@@ -626,7 +670,7 @@ static int launch_filtrar(icm_handle* h, hipStream_t fs) {
     TIMED(h, KID_FILTRAR, (k_fl_pairs<<<nblocks_threads(L), kBlock, 0, fs>>>(fa)));
     TIMED(h, KID_FILTRAR, (k_fl_finalize<<<nb, kFB, 0, fs>>>(fa)));
     // the grid's size is only known on the device: one thread per cell of the capacity
-    TIMED(h, KID_NEIGH, (k_neigh_table<<<nblocks_threads(h->max_cells), kBlock, 0, fs>>>(GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, nullptr}, h->g_nb.p, h->max_cells)));
+    TIMED(h, KID_NEIGH, (k_neigh_table<<<nblocks_threads(h->max_cells), kBlock, 0, fs>>>(GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, nullptr}, h->g_nb.p, h->max_cells, &h->fl_state.p->abort)));
     HIPCHK(h, hipGetLastError());
     return ICM_OK;
 }
@@ -637,6 +681,7 @@ static int launch_filtrar_merge(icm_handle* h, hipStream_t fs, int n) {
     const int L = (int)h->cfg.L;
     const FiltrarArgs fa = filtrar_args(h);
     const int nb = std::min(kFlMaxBlocks, (L + kFB - 1) / kFB);
+    HIPCHK(h, hipMemsetAsync(h->fl_csize.p, 0, (size_t)L * sizeof(int), fs));   // (members of an oversize component write nothing)
     TIMED(h, KID_FILTRAR, (k_fl_components<<<nblocks_threads(L), kBlock, 0, fs>>>(fa)));
     TIMED(h, KID_FILTRAR, (k_fl_label_flags<<<nblocks_threads(L), kBlock, 0, fs>>>(fa)));
     TIMED(h, KID_FILTRAR, (k_exscan_i32<<<1, 1024, 0, fs>>>(h->fl_isl.p, h->fl_rank.p, n)));
@@ -656,6 +701,7 @@ int icm_sweep_local(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_local: no state (icm_set_state)");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     // pose 0 without kept beams: the reference returns its inputs untouched
     // (scripts/ICM_ROS.py:133-135).  Every rank sees the same scan 0 only if it owns it; the
@@ -837,6 +883,36 @@ int icm_sweep_targets(icm_handle* h) {
     return ICM_OK;
 }
 
+// Both colours of the poses [g.t0, g.t1) in one launch (k_solve_m_fused) plus the fix-up launch for
+// even waves that deferred, on stream st.
+static int launch_fused_solve(icm_handle* h, const SolveArgs& a, SolveSeg g, hipStream_t st) {
+    const int64_t npc = (g.t1 - g.t0) / 2 + 1;   // poses per colour (upper bound)
+    const bool quad = h->solve_quad == 1 || (h->solve_quad < 0 && npc * 4 <= (int64_t)1024 * kWave);
+    const int ppw = quad ? kWave / 4 : kWave;
+    const int nwv = (int)((npc + ppw - 1) / ppw);
+    if (h->solve_flag_waves < nwv) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // (re-allocation: nothing may still be polling the old flags)
+        if (h->solve_stream) HIPCHK(h, hipStreamSynchronize(h->solve_stream));
+        HIPCHK(h, h->solve_flags.reserve(2 * (size_t)nwv));
+        HIPCHK(h, h->solve_ndef.reserve(1));
+        HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, 2 * (size_t)nwv * sizeof(int), st));
+        HIPCHK(h, hipMemsetAsync(h->solve_ndef.p, 0, sizeof(unsigned long long), st));
+        h->solve_flag_waves = nwv;
+        h->solve_epoch = 0;
+    }
+    ++h->solve_epoch;   // (flags hold the epoch of the launch that set them: no reset between launches)
+    int* const deferred = h->solve_flags.p + h->solve_flag_waves;
+    if (quad) {
+        TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nblocks_waves(2 * nwv), kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->solve_epoch, h->fused_spin_limit, deferred)));
+        TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_deferred<true><<<nblocks_waves(nwv), kBlock, 0, st>>>(a, g, nwv, deferred, h->solve_ndef.p)));
+    } else {
+        TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nblocks_waves(2 * nwv), kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->solve_epoch, h->fused_spin_limit, deferred)));
+        TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_deferred<false><<<nblocks_waves(nwv), kBlock, 0, st>>>(a, g, nwv, deferred, h->solve_ndef.p)));
+    }
+    HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
 int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: no state");
@@ -864,27 +940,8 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         else TIMED(h, KID_SOLVE, (k_solve_m_sequential<<<1, kWave, 0, h->stream>>>(a)));
     } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->world == 1 && h->t_begin == 0 && h->form == 0 && h->fuse_colours) {
         // both colours of an unsharded sweep in one launch, even waves chase the odd ones
-        const int64_t npc = h->nloc / 2 + 1;   // poses per colour (upper bound)
-        const bool quad = h->solve_quad == 1 || (h->solve_quad < 0 && npc * 4 <= (int64_t)1024 * kWave);
-        const int ppw = quad ? kWave / 4 : kWave;
-        const int nwv = (int)((npc + ppw - 1) / ppw);
-        if (h->solve_flag_waves < nwv) {
-            HIPCHK(h, h->solve_flags.reserve(2 * (size_t)nwv));
-            HIPCHK(h, h->solve_ndef.reserve(1));
-            HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, 2 * (size_t)nwv * sizeof(int), h->stream));
-            HIPCHK(h, hipMemsetAsync(h->solve_ndef.p, 0, sizeof(unsigned long long), h->stream));
-            h->solve_flag_waves = nwv;
-            h->solve_epoch = 0;
-        }
-        ++h->solve_epoch;   // (flags hold the epoch of the launch that set them: no reset between launches)
-        int* const deferred = h->solve_flags.p + h->solve_flag_waves;
-        if (quad) {
-            TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->fused_spin_limit, deferred)));
-            TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_deferred<true><<<nblocks_waves(nwv), kBlock, 0, h->stream>>>(a, nwv, deferred, h->solve_ndef.p)));
-        } else {
-            TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nblocks_waves(2 * nwv), kBlock, 0, h->stream>>>(a, nwv, h->solve_flags.p, h->solve_epoch, h->fused_spin_limit, deferred)));
-            TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_deferred<false><<<nblocks_waves(nwv), kBlock, 0, h->stream>>>(a, nwv, deferred, h->solve_ndef.p)));
-        }
+        int rc = launch_fused_solve(h, a, SolveSeg{0, (int)h->nloc, 0, nullptr}, h->stream);
+        if (rc) return rc;
     } else if (schedule == ICM_SCHEDULE_REDBLACK) {
         const int nw = (int)(h->nloc / 2 + 1);
         for (int col = 1; col >= 0; --col) {
@@ -994,6 +1051,7 @@ int icm_snapshot_state(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_snapshot_state: no state (icm_set_state)");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     const size_t T = (size_t)h->T, L = (size_t)h->cfg.L, nc = (size_t)h->max_cells;
     icm_handle::Snapshot& sn = h->snap;
     HIPCHK(h, sn.x.reserve(3 * T)); HIPCHK(h, sn.mapx.reserve(L)); HIPCHK(h, sn.mapy.reserve(L)); HIPCHK(h, sn.counts_new.reserve(L));
@@ -1020,6 +1078,7 @@ int icm_restore_state(icm_handle* h) {
     const size_t T = (size_t)h->T, L = (size_t)h->cfg.L, nc = (size_t)h->max_cells;
     if (!sn.valid || sn.x.cap < 3 * T || sn.g_nb.cap < nc) FAIL(h, ICM_ERR_ARG, "icm_restore_state: no snapshot of this sequence (icm_snapshot_state)");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     hipStream_t st = h->stream;   // stream-ordered behind the last sweep: no synchronisation needed
     HIPCHK(h, hipMemcpyAsync(h->x, sn.x.p, 3 * T * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->mapx.p, sn.mapx.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1034,18 +1093,208 @@ int icm_restore_state(icm_handle* h) {
     return ICM_OK;
 }
 
-int icm_sweep_device(icm_handle* h, int schedule) {
+static SolveArgs solve_args(icm_handle* h) {
+    SolveArgs a;
+    a.x = h->x; a.x0 = h->x0.p; a.odo = h->odo.p; a.u = h->u.p;
+    a.T = (int)h->T; a.t_begin = (int)h->t_begin; a.nloc = (int)h->nloc;
+    a.boff = h->boff.p; a.bx = h->bx.p; a.by = h->by.p; a.btx = h->btx.p; a.bty = h->bty.p;
+    a.per_beam = h->per_beam ? 1 : 0;
+    a.ent_off = h->ent_off.p; a.e_k = h->e_k.p; a.e_b = h->e_b.p;
+    a.tgt = h->tgt.p; a.pose_c = h->pose_c.p; a.pose_m = h->pose_m.p;
+    a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
+    a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
+    a.diag = nullptr;
+    return a;
+}
+
+// Where the pipelined sweep cuts the sequence: at a superchunk boundary (so that chunks, records and
+// matrix rows split cleanly) and therefore at an even pose -- the first segment ends on an odd
+// pose, whose even neighbours on both sides it reads as OLD values, and the second segment's first
+// (even) pose reads that finished odd pose: the red-black order of the whole sequence is kept
+// (k_solve_m_fused, SolveSeg).  0 = the sequence is too short to cut.
+static int pipeline_split_super(const icm_handle* h) {
+    if (h->nsuper < 2) return 0;
+    const int s = h->nsuper / 2;
+    const int64_t M = (int64_t)s * h->chunk_group * h->chunk_poses;
+    return (M >= 2 && M + 1 < h->nloc) ? s : 0;
+}
+
+static bool pipeline_applies(const icm_handle* h, int schedule) {
+    return h->pipeline && h->pipe_ok && schedule == ICM_SCHEDULE_REDBLACK && h->world == 1 && h->t_begin == 0 && h->nloc == h->T &&
+           h->form == 0 && h->fuse_colours && !h->timing && !h->debug && !h->per_beam && !h->brute && h->entry_path != 0 &&
+           h->hier_ok && h->gpu_filtrar && !h->x_external && pipeline_split_super(h) > 0;
+}
+
+static int icm_sweep_classic(icm_handle* h, int schedule) {
     int rc;
+    h->pipe_used = 0;
     if ((rc = icm_sweep_local(h))) return rc;
     if ((rc = icm_sweep_targets(h))) return rc;
     if ((rc = icm_sweep_solve(h, schedule, -1))) return rc;
     return icm_sweep_finish(h);
 }
 
+// One red-black sweep with the two time segments software-pipelined over two streams:
+//   main stream   A/B/moments(seg 0) | A/B/moments(seg 1)                 | next sweep: A/B/moments(seg 0) ...
+//   solve stream                     | solves(seg 0)      | solves(seg 1) ...
+// The pose solves are bounded by the serial Nelder-Mead chain of their slowest wave (one wave per
+// SIMD at half the FP64 issue rate), phase A/B by vector issue: side by side they fill the chip.
+// Same kernels, same arithmetic, same order per pose as the unsegmented sweep -- bit-identical results.
+static int icm_sweep_pipelined(icm_handle* h) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nloc = (int)h->nloc, L = (int)h->cfg.L;
+    h->scan0_empty = (h->h_boff[1] == h->h_boff[0]);
+    if (h->scan0_empty) return join_solves(h);
+    if (h->h_boff[(size_t)nloc] == h->h_boff[(size_t)nloc - 1])
+        FAIL(h, ICM_ERR_INDEX, "sweep: the last pose has no kept beams (the reference raises IndexError at scripts/ICM_ROS.py:144)");
+    hipStream_t X = h->stream, Y = h->solve_stream, Cs = h->copy_stream;
+    const int CH = h->chunk_poses, G = h->chunk_group, S = h->nsuper, NC = h->nchunks;
+    const int s_split = pipeline_split_super(h), c_split = s_split * G, M = c_split * CH;
+    const int nrec = NC * kT1;
+    double* const pre = reinterpret_cast<double*>(h->e_w.p);
+    const size_t nzs = (size_t)std::max<int64_t>(h->nnz, 1) + kWave;
+    double* const ms = h->ms.p;
+    const size_t msn = (size_t)S * (size_t)L;
+    double* const ro = h->rec_off.p;
+    HIPCHK(h, h->x_bak.reserve(3 * (size_t)M));
+    HIPCHK(h, h->l3_carry.reserve(3 * (size_t)L));
+    HIPCHK(h, h->scan_carry.reserve(2));
+    {   // completion flags of the one-launch solves: sized once for the longer segment
+        const int64_t npc = std::max<int64_t>(M, nloc - M) / 2 + 1;
+        const int nwv = (int)((npc + 15) / 16) + 1;   // (enough for the quad form, 16 poses per wave)
+        if (h->solve_flag_waves < nwv) {
+            HIPCHK(h, hipStreamSynchronize(Y));
+            HIPCHK(h, hipStreamSynchronize(X));
+            HIPCHK(h, h->solve_flags.reserve(2 * (size_t)nwv));
+            HIPCHK(h, h->solve_ndef.reserve(1));
+            HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, 2 * (size_t)nwv * sizeof(int), Y));
+            HIPCHK(h, hipMemsetAsync(h->solve_ndef.p, 0, sizeof(unsigned long long), Y));
+            h->solve_flag_waves = nwv;
+            h->solve_epoch = 0;
+        }
+    }
+    h->lact0 = (int)h->lact;
+    h->assoc_kept = false;
+    h->ms_clean = false;
+    const SolveArgs sa = solve_args(h);
+    GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p};
+    HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), X));
+    for (int seg = 0; seg < 2; ++seg) {
+        const int t0 = seg ? M : 0, t1 = seg ? nloc : M, nseg = t1 - t0;
+        const int c0 = seg ? c_split : 0, c1 = seg ? NC : c_split;
+        const int s0 = seg ? s_split : 0, s1 = seg ? S : s_split;
+        // this segment's poses (and the buffers its solves read) must be final: the previous sweep's solves of it
+        if (h->solves_in_flight) HIPCHK(h, hipStreamWaitEvent(X, h->ev_s[seg], 0));
+        if (seg == 0) HIPCHK(h, hipMemcpyAsync(h->x_bak.p, h->x, 3 * (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, X));
+        const int nbw = nblocks_waves(nseg);
+#define ASSOC_SEG(HS)                                                                                                 \
+    k_assoc_group<false, false, HS><<<nbw, kBlock, 0, X>>>(h->x, h->x0.p, t0, nseg, h->boff.p + t0, h->bx.p, h->by.p, gv,  \
+        h->cfg.dist_thr, h->thr2, h->label.p, h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p + t0, \
+        h->isnew.p + t0, h->flags.p)
+        if (h->hash_slots == 128) ASSOC_SEG(128); else ASSOC_SEG(256);
+#undef ASSOC_SEG
+        const int ntiles = (nseg + kScanTile - 1) / kScanTile;
+        k_scan_tiles<<<ntiles, kBlock, 0, X>>>(h->nent.p + t0, h->isnew.p + t0, h->ent_off.p + t0, h->new_rank.p + t0, h->scan_tot.p, nseg);
+        k_scan_fix<<<ntiles, kBlock, 0, X>>>(h->ent_off.p + t0, h->new_rank.p + t0, h->scan_tot.p, nseg, ntiles,
+                                             seg ? h->scan_carry.p : nullptr, seg ? nullptr : h->scan_carry.p);
+#define CHUNK_L1(CHV)                                                                                                  \
+    k_chunk_l1<CHV><<<nblocks_waves(c1 - c0), kBlock, 0, X>>>(h->x, h->x0.p, 0, nloc, c1, h->boff.p, h->nent.p, h->ent_off.p, \
+        h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs,                          \
+        reinterpret_cast<unsigned*>(pre + 2 * nzs), reinterpret_cast<unsigned char*>(h->e_val.p), h->rec_label.p, h->rec_s.p, \
+        h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave, c0)
+        if (CH == 64) CHUNK_L1(64); else if (CH == 32) CHUNK_L1(32); else CHUNK_L1(16);
+#undef CHUNK_L1
+        k_chunk_l2<<<s1 - s0, kT1, 0, X>>>(NC, G, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
+                                           ro, ro + nrec, ro + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->flags.p, s0, 1);
+        k_lm_l3<<<nblocks_threads(L), kBlock, 0, X>>>(S, L, h->lact0, h->new_rank.p + t1, ms, ms + msn, ms + 2 * msn, nullptr,
+                                                      h->y_raw.p, h->cnt_raw.p, h->ent_off.p + t1, h->flags.p, s0, s1,
+                                                      seg ? h->l3_carry.p : nullptr, seg ? nullptr : h->l3_carry.p, seg);
+        if (seg) HIPCHK(h, hipEventRecord(h->ev_map, X));   // raw map, counts and flags are final: the copy stream takes them from here
+        k_rec_push<<<nblocks_threads((int64_t)(c1 - c0) * kT1), kBlock, 0, X>>>(c1 * kT1, G, L, h->rec_label.p, ms, ms + msn, ms + 2 * msn,
+                                                                               nullptr, nullptr, nullptr, ro, ro + nrec, ro + 2 * (size_t)nrec, c0 * kT1);
+        k_pose_moments_h<<<nblocks_threads((int64_t)nseg * 16), kBlock, 0, X>>>(
+            h->x, h->x0.p, 0, nloc, h->boff.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, pre, pre + nzs,
+            reinterpret_cast<const unsigned*>(pre + 2 * nzs), reinterpret_cast<const unsigned char*>(h->e_val.p), CH, ro, ro + nrec,
+            ro + 2 * (size_t)nrec, h->pose_m.p, nullptr, t0, t1);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev_m[seg], X));
+        if (seg == 0) {   // its solves start beside the second segment's phase A/B
+            HIPCHK(h, hipStreamWaitEvent(Y, h->ev_m[0], 0));
+            int rc = launch_fused_solve(h, sa, SolveSeg{0, M, 0, nullptr}, Y);
+            if (rc) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_s[0], Y));
+        }
+    }
+    // Everything else of the sweep is queued WITHOUT a host look at the counts and flags: the kernels
+    // that would replace state (second segment's solves, Mapa.filtrar) check the sweep's flags themselves
+    // and leave the state alone if a table overflowed or the labels exceed L.
+    HIPCHK(h, hipStreamWaitEvent(Y, h->ev_m[1], 0));
+    {
+        int rc = launch_fused_solve(h, sa, SolveSeg{M, nloc, 1, h->flags.p}, Y);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->ev_s[1], Y));
+    h->solves_in_flight = true;
+    // raw map download, the four counters, Mapa.filtrar + search grid: copy stream, beside moments / solves
+    const size_t Ls = (size_t)L;
+    HIPCHK(h, hipStreamWaitEvent(Cs, h->ev_map, 0));
+    {
+        int rc = launch_filtrar(h, Cs, true);   // (first: the next sweep's phase A waits for the new map, not for the downloads)
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->pin_i, h->flags.p + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, Cs));
+    HIPCHK(h, hipMemcpyAsync(h->pin_d, h->y_raw.p, 2 * Ls * sizeof(double), hipMemcpyDeviceToHost, Cs));
+    HIPCHK(h, hipMemcpyAsync(h->pin_d + 2 * Ls, h->cnt_raw.p, Ls * sizeof(double), hipMemcpyDeviceToHost, Cs));
+    HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, Cs));
+    HIPCHK(h, hipEventRecord(h->ev_copied, Cs));
+    h->map_copy_pending = true;
+    // the one host wait of the sweep (the solves are still running)
+    HIPCHK(h, hipEventSynchronize(h->ev_copied));
+    h->E = h->pin_i[0];
+    h->n_new_loc = h->pin_i[1];
+    if (h->pin_i[2] || h->pin_i[3]) {
+        // a per-pose or per-chunk table overflowed: this map is too dense for the pipelined form.  The
+        // map state and the second segment's poses were left alone (device-side checks); the first
+        // segment's solves have run on incomplete targets: put its poses back and take the unsegmented
+        // sweep, which sizes its tables / falls back to the sort-based pipeline itself.
+        HIPCHK(h, hipStreamSynchronize(Y));
+        h->solves_in_flight = false;
+        h->map_copy_pending = false;
+        HIPCHK(h, hipMemcpyAsync(h->x, h->x_bak.p, 3 * (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, X));
+        h->pipe_ok = false;
+        return icm_sweep_classic(h, ICM_SCHEDULE_REDBLACK);
+    }
+    if ((int64_t)h->lact0 + h->n_new_loc > L) {
+        h->map_copy_pending = false;
+        int rcj = join_solves(h);
+        if (rcj) return rcj;
+        FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
+    }
+    h->path_used = 1;
+    h->pipe_used = 1;
+    return icm_sweep_finish(h);
+}
+
+int icm_sweep_device(icm_handle* h, int schedule) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_device: no state (icm_set_state)");
+    if (pipeline_applies(h, schedule)) return icm_sweep_pipelined(h);
+    return icm_sweep_classic(h, schedule);
+}
+
+int icm_set_pipeline(icm_handle* h, int on) {
+    if (!h) return ICM_ERR_ARG;
+    h->pipeline = on != 0;
+    return ICM_OK;
+}
+
+int icm_get_pipeline_used(const icm_handle* h) { return h ? h->pipe_used : ICM_ERR_ARG; }
+
 int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out, int64_t* K_out) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_get_state: no state");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     {
         int rc = sync_host_map(h);
         if (rc) return rc;
@@ -1090,6 +1339,7 @@ int icm_get_association(icm_handle* h, int32_t* labels, double* target_x, double
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_get_association: no sweep has run");
     if (!h->assoc_kept) FAIL(h, ICM_ERR_ARG, "icm_get_association: enable icm_set_debug before the sweep");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t nz = (size_t)h->nnz;
     if (!nz) return ICM_OK;
@@ -1187,7 +1437,7 @@ int icm_filtrar(const icm_config* cfg, const double* y, const double* counts, in
     return filtrar_host(*cfg, y, counts, lact, y_out, counts_out, lact_out, g_create_err);
 }
 
-static int launch_filtrar(icm_handle* h, hipStream_t fs);
+static int launch_filtrar(icm_handle* h, hipStream_t fs, bool guarded);
 static int launch_filtrar_merge(icm_handle* h, hipStream_t fs, int n);
 
 int icm_filtrar_device(icm_handle* h, const double* y, const double* counts, int64_t lact, double* y_out,
@@ -1198,6 +1448,7 @@ int icm_filtrar_device(icm_handle* h, const double* y, const double* counts, int
     if (lact < 0 || lact > (int64_t)L) FAIL(h, ICM_ERR_ARG, "icm_filtrar_device: landmarks_actuales outside [0, L]");
     if (h->world > 1) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_filtrar_device: not on a handle bound to a multi-rank exchange");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     {
         int rc = reserve_map_buffers(h);
         if (rc) return rc;
@@ -1209,7 +1460,7 @@ int icm_filtrar_device(icm_handle* h, const double* y, const double* counts, int
     HIPCHK(h, hipMemsetAsync(h->new_rank.p + h->nloc, 0, sizeof(int), st));
     const int lact0_keep = h->lact0;
     h->lact0 = (int)lact;
-    int rc = launch_filtrar(h, st);
+    int rc = launch_filtrar(h, st, false);
     int info[4] = {0, 2, 0, 0};
     if (!rc) {
         HIPCHK(h, hipMemcpyAsync(info, h->fl_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
@@ -1350,6 +1601,7 @@ int icm_init_pass(icm_handle* h, const double* x0, double* y, double* counts, in
     const size_t lds = (size_t)maxb * (4 * sizeof(double) + sizeof(int));
     if (lds > 160 * 1024) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_init_pass: too many kept beams per scan for the LDS staging");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     DevBuf<double> dx, dy, dc;
     DevBuf<int> di;
     HIPCHK(h, dx.reserve(3 * T)); HIPCHK(h, dy.reserve(2 * L)); HIPCHK(h, dc.reserve(L)); HIPCHK(h, di.reserve(2));
@@ -1424,6 +1676,7 @@ int icm_get_solve_diag(icm_handle* h, double* out) {
     if (!h || !out) return ICM_ERR_ARG;
     if (!h->diag.p) FAIL(h, ICM_ERR_ARG, "icm_get_solve_diag: enable icm_set_debug before the sweep");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->diag.p, 3 * (size_t)h->T * sizeof(double), hipMemcpyDeviceToHost));
     return ICM_OK;

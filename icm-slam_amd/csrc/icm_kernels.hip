@@ -58,10 +58,13 @@ __device__ __forceinline__ double row_sum16(double v) {  // sum over the 16 lane
 // k_scan_fix:   adds the totals of the preceding tiles; out[n] = grand total.
 // ---------------------------------------------------------------------------------------
 constexpr int kScanTile = 1024;
+// abort (nullable): a device word; non-zero = leave the outputs alone (a sweep queued without a host
+// check in between must not touch the map state after a table overflow).
 __global__ __launch_bounds__(kBlock) void k_scan_tiles(const int* __restrict__ a, const int* __restrict__ b,
                                                        int* __restrict__ oa, int* __restrict__ ob,
-                                                       int* __restrict__ tot, int n) {
+                                                       int* __restrict__ tot, int n, const int* __restrict__ abort = nullptr) {
     __shared__ int wa[kWavesPerBlock], wb[kWavesPerBlock];
+    if (abort && *abort) return;
     const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
     int va[4], vb[4];
 #pragma unroll
@@ -106,9 +109,14 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(const int* __restrict__ a
     }
 }
 
+// carry_in (nullable): totals of everything scanned before this range (a sequence scanned in
+// consecutive ranges); carry_out (nullable): grand total including the carry.
 __global__ __launch_bounds__(kBlock) void k_scan_fix(int* __restrict__ oa, int* __restrict__ ob,
-                                                     const int* __restrict__ tot, int n, int ntiles) {
+                                                     const int* __restrict__ tot, int n, int ntiles,
+                                                     const int* __restrict__ carry_in = nullptr, int* __restrict__ carry_out = nullptr,
+                                                     const int* __restrict__ abort = nullptr) {
     __shared__ int ra[kBlock], rb[kBlock];
+    if (abort && *abort) return;
     // sum of the totals of all tiles before this one (and, for the last block, the grand total)
     const int mine = blockIdx.x;
     int sa = 0, sb = 0, ga = 0, gb = 0;
@@ -131,7 +139,8 @@ __global__ __launch_bounds__(kBlock) void k_scan_fix(int* __restrict__ oa, int* 
         }
         __syncthreads();
     }
-    const int offa = ra[0], offb = rb[0];
+    const int ca = carry_in ? carry_in[0] : 0, cb = carry_in ? carry_in[1] : 0;
+    const int offa = ra[0] + ca, offb = rb[0] + cb;
     const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -152,8 +161,12 @@ __global__ __launch_bounds__(kBlock) void k_scan_fix(int* __restrict__ oa, int* 
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            oa[n] = ra[0];
-            ob[n] = rb[0];
+            oa[n] = ra[0] + ca;
+            ob[n] = rb[0] + cb;
+            if (carry_out) {
+                carry_out[0] = ra[0] + ca;
+                carry_out[1] = rb[0] + cb;
+            }
         }
     }
 }
@@ -430,7 +443,9 @@ __device__ __forceinline__ int assoc_grid(const GridView& g, const GridParams& g
 
 // Fills the neighbourhood records of every cell of the current grid (one thread per cell;
 // launched with the cell CAPACITY because the grid's size may only be known on the device).
-__global__ __launch_bounds__(kBlock) void k_neigh_table(GridView g, NeighRec* __restrict__ out, int max_cells) {
+__global__ __launch_bounds__(kBlock) void k_neigh_table(GridView g, NeighRec* __restrict__ out, int max_cells,
+                                                        const int* __restrict__ abort = nullptr) {
+    if (abort && *abort) return;
     const GridParams gp = *g.par;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= gp.nx * gp.ny || c >= max_cells) return;
@@ -1073,10 +1088,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                                                      unsigned* __restrict__ pre_n, unsigned char* __restrict__ e_rec,
                                                      int* __restrict__ rec_label, double* __restrict__ rec_sx,
                                                      double* __restrict__ rec_sy, double* __restrict__ rec_n,
-                                                     int* __restrict__ flags, size_t dump) {
+                                                     int* __restrict__ flags, size_t dump, int c_begin = 0) {
     __shared__ ChunkTable tables[kWavesPerBlock];
     const int lane = lane_id();
-    const int c = blockIdx.x * kWavesPerBlock + wave_in_block();
+    const int c = c_begin + blockIdx.x * kWavesPerBlock + wave_in_block();   // chunks [c_begin, nchunks)
     if (c >= nchunks) return;
     ChunkTable& T = tables[wave_in_block()];
     for (int s = lane; s < kT1; s += kWave) {
@@ -1206,11 +1221,20 @@ __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, con
                                                   const double* __restrict__ rec_n, double* __restrict__ off_x,
                                                   double* __restrict__ off_y, double* __restrict__ off_n,
                                                   double* __restrict__ ms_x, double* __restrict__ ms_y,
-                                                  double* __restrict__ ms_n, int* __restrict__ flags) {
+                                                  double* __restrict__ ms_n, int* __restrict__ flags, int sc_begin = 0,
+                                                  int zero_row = 0) {
     __shared__ int key[kT2];
     __shared__ double sx[kT2], sy[kT2], sn[kT2];
     __shared__ int used;
-    const int tid = threadIdx.x, sc = blockIdx.x;
+    const int tid = threadIdx.x, sc = sc_begin + blockIdx.x;
+    // this superchunk's row of the dense matrix takes its landmarks' totals at the end; zero_row: clear
+    // it first (otherwise the host has cleared the whole matrix, on a side stream under the solves)
+    if (zero_row)
+        for (int k = tid; k < L; k += kT1) {
+            ms_x[(size_t)sc * L + k] = 0.0;
+            ms_y[(size_t)sc * L + k] = 0.0;
+            ms_n[(size_t)sc * L + k] = 0.0;
+        }
     for (int s = tid; s < kT2; s += kT1) {
         key[s] = kEmpty;
         sx[s] = 0.0;
@@ -1287,36 +1311,47 @@ __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, con
     }
 }
 
-// Level 3: exclusive prefix down each landmark's column of the (zero-initialised) matrix.
-// stats != nullptr: the rank's totals for the exchange [sx(L) | sy(L) | n(L)]; else the raw map.
+// Level 3: exclusive prefix down each landmark's column of the matrix, rows [row_begin, row_end).
+// A sweep may take the rows in consecutive ranges (time segments): carry_in = the column sums of the
+// rows before (null: none), carry_out = those through row_end (null: not needed).  final: the totals
+// go out -- stats != nullptr: the rank's totals for the exchange [sx(L) | sy(L) | n(L)]; else the raw map.
 __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, const int* __restrict__ n_new_dev,
                                                   double* __restrict__ ms_x, double* __restrict__ ms_y,
                                                   double* __restrict__ ms_n, double* __restrict__ stats,
                                                   double* __restrict__ y_raw, double* __restrict__ cnt_raw,
-                                                  const int* __restrict__ n_ent_dev, int* __restrict__ flags) {
+                                                  const int* __restrict__ n_ent_dev, int* __restrict__ flags,
+                                                  int row_begin = 0, int row_end = -1, const double* __restrict__ carry_in = nullptr,
+                                                  double* __restrict__ carry_out = nullptr, int final = 1) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i == 0) {  // what the host reads back at its one synchronisation of the sweep, in one 16-byte copy
+    if (row_end < 0) row_end = nsuper;
+    if (i == 0 && final) {  // what the host reads back at its one synchronisation of the sweep, in one 16-byte copy
         flags[4] = *n_ent_dev;
         flags[5] = *n_new_dev;
         flags[6] = flags[0];
         flags[7] = flags[1];
+        flags[2] = lact0 + *n_new_dev > L ? 1 : 0;   // labels beyond the map capacity (the reference's IndexError)
     }
     if (i >= L) return;
     double ax = 0.0, ay = 0.0, an = 0.0;
+    if (carry_in) {
+        ax = carry_in[i];
+        ay = carry_in[L + i];
+        an = carry_in[2 * (size_t)L + i];
+    }
     if (i < lact0 + *n_new_dev) {  // columns of labels that do not exist are all zero
         constexpr int kBatch = 8;   // loads of a batch are issued together, then the stores
-        for (int s0 = 0; s0 < nsuper; s0 += kBatch) {
+        for (int s0 = row_begin; s0 < row_end; s0 += kBatch) {
             double vx[kBatch], vy[kBatch], vn[kBatch];
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
-                const size_t q = (size_t)min(s0 + b, nsuper - 1) * L + i;
+                const size_t q = (size_t)min(s0 + b, row_end - 1) * L + i;
                 vx[b] = ms_x[q];
                 vy[b] = ms_y[q];
                 vn[b] = ms_n[q];
             }
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
-                if (s0 + b < nsuper) {
+                if (s0 + b < row_end) {
                     const size_t q = (size_t)(s0 + b) * L + i;
                     ms_x[q] = ax;
                     ms_y[q] = ay;
@@ -1328,6 +1363,12 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
             }
         }
     }
+    if (carry_out) {
+        carry_out[i] = ax;
+        carry_out[L + i] = ay;
+        carry_out[2 * (size_t)L + i] = an;
+    }
+    if (!final) return;
     if (stats) {
         stats[i] = ax;
         stats[L + i] = ay;
@@ -1346,8 +1387,8 @@ __global__ __launch_bounds__(kBlock) void k_rec_push(int nrec, int G, int L, con
                                                      const double* __restrict__ ms_n, const double* __restrict__ rank_x,
                                                      const double* __restrict__ rank_y, const double* __restrict__ rank_n,
                                                      double* __restrict__ off_x, double* __restrict__ off_y,
-                                                     double* __restrict__ off_n) {
-    const int r = blockIdx.x * kBlock + threadIdx.x;
+                                                     double* __restrict__ off_n, int r_begin = 0) {
+    const int r = r_begin + blockIdx.x * kBlock + threadIdx.x;   // records [r_begin, nrec)
     if (r >= nrec) return;
     const int lab = rec_label[r];
     if (lab == kEmpty || lab >= L) return;
@@ -1396,7 +1437,8 @@ struct FlState {
     int same;      // survivors coincident with another one
     int host;      // the host routine must take over
     int n_ref;     // landmarks after merging
-    int pad[3];
+    int abort;     // the sweep's tables overflowed / its labels exceed L: leave the map state alone
+    int pad[2];
     GridParams gp;
     int part_keep[kFlMaxBlocks];
     double part_mm[4 * kFlMaxBlocks];   // per block: min x, max x, min y, max y of its points
@@ -1407,6 +1449,7 @@ struct FiltrarArgs {
     const double* cnt_raw;  // (L)
     const double* stats_all;  // sharded: per-rank headers hold the new-landmark counts
     const int* n_new_dev;     // single rank: landmarks created this sweep (device word)
+    const int* sweep_flags;   // nullable: the sweep's flags ([0], [1] table overflows, [2] labels beyond L)
     int L, lact0, world, stride;
     double cota, thr;
     int max_cells;
@@ -1534,7 +1577,10 @@ __global__ __launch_bounds__(kFB) void k_fl_count(FiltrarArgs a, int chunk) {
     fl_block_extent(x0, x1, y0, y1, red, a.st->part_mm + 4 * b);
     if (threadIdx.x == 0) {
         a.st->part_keep[b] = tot;
-        if (b == 0) a.st->close = a.st->same = a.st->host = 0;
+        if (b == 0) {
+            a.st->close = a.st->same = a.st->host = 0;
+            a.st->abort = a.sweep_flags ? (a.sweep_flags[0] | a.sweep_flags[1] | a.sweep_flags[2]) : 0;
+        }
     }
 }
 
@@ -1593,7 +1639,7 @@ __global__ __launch_bounds__(kBlock) void k_fl_cell_count(FiltrarArgs a, const d
 __global__ __launch_bounds__(kBlock) void k_fl_fill(FiltrarArgs a, const double* __restrict__ x, const double* __restrict__ y,
                                                     const int* __restrict__ n_dev) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= *n_dev) return;
+    if (i >= *n_dev || a.st->abort) return;
     const int p = atomicAdd(&a.cell_fill[a.cid[i]], 1);
     a.g_lm[p] = LmRec{x[i], y[i], i, 0, 0, 0};
 }
@@ -1601,7 +1647,7 @@ __global__ __launch_bounds__(kBlock) void k_fl_fill(FiltrarArgs a, const double*
 // nearest other survivor (smallest index on ties, like np.argmin over the column)
 __global__ __launch_bounds__(kBlock) void k_fl_pairs(FiltrarArgs a) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.st->n) return;
+    if (i >= a.st->n || a.st->abort) return;
     const GridParams gp = a.st->gp;
     const double xi = a.px[i], yi = a.py[i];
     const int cx = grid_cell(xi, gp.gx0, gp.inv, gp.nx), cy = grid_cell(yi, gp.gy0, gp.inv, gp.ny);
@@ -1628,6 +1674,14 @@ __global__ __launch_bounds__(kBlock) void k_fl_pairs(FiltrarArgs a) {
 }
 
 __global__ __launch_bounds__(kFB) void k_fl_finalize(FiltrarArgs a) {
+    if (a.st->abort) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.info[0] = 0;
+            a.info[1] = 3;   // nothing touched: the host re-runs the sweep
+            a.info[2] = 0;
+        }
+        return;
+    }
     const int n = a.st->n;
     const bool host = n == 0 || a.st->same > 0;
     const bool merge = a.st->close > 0;
@@ -1752,11 +1806,15 @@ __global__ __launch_bounds__(kBlock) void k_fl_label_flags(FiltrarArgs a) {   //
 __global__ __launch_bounds__(kBlock) void k_fl_gather(FiltrarArgs a) {
     const int l = blockIdx.x * kBlock + threadIdx.x;
     const int n = a.st->n;
+    if (a.st->host) {   // a component beyond kCompMax: labels are incomplete, the host routine takes over;
+        if (l == 0) a.st->n_ref = 0;   // the grid chain queued behind finds nothing to do
+        return;
+    }
     const int n_ref = a.rank[n];
     if (l == 0) a.st->n_ref = n_ref;
     if (l < a.L && l >= n_ref) a.counts_new[l] = 0.0;
     if (l >= n || a.csize[l] == 0) return;
-    const int r = a.rank[l], k = a.csize[l];
+    const int r = a.rank[l], k = min(a.csize[l], kCompMax);
     double cs = 0.0, sx = 0.0, sy = 0.0;
     for (int q = 0; q < k; ++q) {   // members in ascending order, like the boolean mask
         const int m = a.comp[(size_t)l * kCompStride + q];
@@ -1935,10 +1993,10 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
                                                            const unsigned* __restrict__ pre_n, const unsigned char* __restrict__ e_rec, int chunk_poses,
                                                            const double* __restrict__ off_x, const double* __restrict__ off_y,
                                                            const double* __restrict__ off_n, double* __restrict__ pose_m,
-                                                           double2* __restrict__ tgt_out) {
+                                                           double2* __restrict__ tgt_out, int tl_begin = 0, int tl_end = -1) {
     const int sub = threadIdx.x & 15;
-    const int tl = (blockIdx.x * kBlock + threadIdx.x) >> 4;
-    const bool live = tl < nloc;
+    const int tl = tl_begin + ((blockIdx.x * kBlock + threadIdx.x) >> 4);   // poses [tl_begin, tl_end)
+    const bool live = tl < (tl_end < 0 ? nloc : tl_end);
     double px = 0.0, py = 0.0, th = 0.0;
     int j0 = 0, e0 = 0, n = 0;
     if (live) {
@@ -2077,12 +2135,25 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
 // vmcnt(0), then plain loads.  The odd waves that READ an even wave's poses (as the old values of
 // their neighbours) are exactly the two it waits for, so nothing is overwritten while in use.
 // QUAD: the latency form (one DPP quad per pose, 16 poses per wave) with the same dependency rule.
+// A time segment of the sequence solved by one launch: poses [t0, t1).  shift = 0 for the segment
+// that starts at pose 0 (which is never solved), 1 for a segment that starts at an even pose > 0:
+//   odd poses   o_j = t0 + 1 + 2 j
+//   even poses  e_j = t0 + 2 j + 2 (1 - shift)      -> e_j reads o_{j - shift} and o_{j - shift + 1}
+// (the first even pose of a shift-1 segment reads the last pose of the segment before, which the
+// stream has finished by then).  Splitting the sequence at an even pose keeps the red-black order:
+// every segment's odd poses read only old even poses, its even poses only finished odd ones.
+struct SolveSeg {
+    int t0, t1, shift;
+    const int* abort;   // nullable: the sweep's flags; any of [0..2] set = leave the poses alone
+};
+
 template <bool QUAD>
-__device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, bool even, int wv, int lane) {
+__device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, const SolveSeg& g, bool even, int wv, int lane) {
     constexpr int PPW = QUAD ? kWave / 4 : kWave;   // poses per wave
     const int role = QUAD ? (lane & 3) : 0;
-    const int tg = (even ? 2 : 1) + 2 * (wv * PPW + (QUAD ? lane >> 2 : lane));   // (unsharded: t_begin = 0)
-    if (tg < a.nloc) {   // (whole quads together)
+    const int j = wv * PPW + (QUAD ? lane >> 2 : lane);
+    const int tg = g.t0 + 2 * j + (even ? 2 * (1 - g.shift) : 1);
+    if (tg < g.t1) {   // (whole quads together)
         double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
         double res[3];
         solve_pose_moments<QUAD>(a, tg, prev, res, role);
@@ -2095,19 +2166,22 @@ __device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, bool even, 
 }
 
 template <bool QUAD>
-__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, int* __restrict__ flags, int epoch,
+__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags, int epoch,
                                                           int spin_limit, int* __restrict__ deferred) {
     const int lane = lane_id();
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (gw >= 2 * nw) return;
+    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;   // (uniform over the whole grid)
     const bool even = gw >= nw;
     const int wv = even ? gw - nw : gw;
     if (even) {
         int ready = 1;
         if (lane == 0) {
-            for (int d = 0; d < 2 && wv + d < nw && ready; ++d) {   // odd poses 2j+1, j in [PPW wv, PPW wv + PPW]
+            for (int d = 0; d < 2 && ready; ++d) {   // the (at most) two odd waves that hold this wave's neighbours
+                const int ow = wv + d - g.shift;
+                if (ow < 0 || ow >= nw) continue;
                 int spins = 0;
-                while (__hip_atomic_load(&flags[wv + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                while (__hip_atomic_load(&flags[ow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                     if (++spins > spin_limit) {
                         ready = 0;
                         break;
@@ -2122,7 +2196,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, i
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    solve_wave_poses<QUAD>(a, even, wv, lane);
+    solve_wave_poses<QUAD>(a, g, even, wv, lane);
     if (!even) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -2133,13 +2207,13 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, int nw, i
 
 // The even waves k_solve_m_fused deferred (normally none: every wave returns at once).
 template <bool QUAD>
-__global__ __launch_bounds__(kBlock) void k_solve_m_deferred(SolveArgs a, int nw, int* __restrict__ deferred,
+__global__ __launch_bounds__(kBlock) void k_solve_m_deferred(SolveArgs a, SolveSeg g, int nw, int* __restrict__ deferred,
                                                              unsigned long long* __restrict__ n_deferred) {
     const int lane = lane_id();
     const int wv = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (wv >= nw) return;
     if (!deferred[wv]) return;
-    solve_wave_poses<QUAD>(a, true, wv, lane);
+    solve_wave_poses<QUAD>(a, g, true, wv, lane);
     if (lane == 0) {
         deferred[wv] = 0;
         atomicAdd(n_deferred, 1ull);

@@ -76,6 +76,8 @@ SIGNATURES = {
     "icm_snapshot_state": (C.c_int, [_H]),
     "icm_restore_state": (C.c_int, [_H]),
     "icm_set_colour_fusion": (C.c_int, [_H, C.c_int]),
+    "icm_set_pipeline": (C.c_int, [_H, C.c_int]),
+    "icm_get_pipeline_used": (C.c_int, [_H]),
     "icm_set_fused_spin_limit": (C.c_int, [_H, C.c_int]),
     "icm_get_fused_deferred": (C.c_int, [_H, _lp]),
     "icm_set_entry_path": (C.c_int, [_H, C.c_int]),

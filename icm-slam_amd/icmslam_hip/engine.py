@@ -381,6 +381,15 @@ class SweepEngine:
         """True (default): both colours of an unsharded red-black sweep in one launch."""
         self._chk(self.lib.icm_set_colour_fusion(self.h, int(bool(on))))
 
+    def set_pipeline(self, on):
+        """True: unsharded red-black sweeps run as two time segments pipelined over two streams (default
+        False: measured slower on MI355X, kept as a tested option)."""
+        self._chk(self.lib.icm_set_pipeline(self.h, int(bool(on))))
+
+    def pipeline_used(self):
+        """Did the last sweep run pipelined?"""
+        return self.lib.icm_get_pipeline_used(self.h) == 1
+
     def set_fused_spin_limit(self, polls):
         """Polls an even wave of the one-launch solve waits before deferring to the fix-up launch."""
         self._chk(self.lib.icm_set_fused_spin_limit(self.h, int(polls)))

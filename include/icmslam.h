@@ -216,6 +216,18 @@ int icm_set_solve_lanes(icm_handle *h, int mode);
  * even wave starting as soon as the two odd waves holding its poses' neighbours are done
  * (k_solve_m_fused); 0 = one launch per colour.  Bit-identical results. */
 int icm_set_colour_fusion(icm_handle *h, int on);
+/* Unsharded red-black sweeps on the device-resident state (icm_sweep_device / icm_sweep): 1 =
+ * software-pipelined over two HIP streams -- the sequence is cut at an even pose into
+ * two time segments, and the pose solves of one segment (bounded by their serial Nelder-Mead
+ * chains) run beside the association / running-mean kernels of the other (bounded by vector
+ * issue); 0 (default) = one segment, one stream.  Same kernels and arithmetic per pose:
+ * bit-identical results.  Measured on MI355X the pipelined form is SLOWER (0.71 vs 0.62 ms per S2
+ * sweep: both halves are vector-issue hungry, so side by side each runs 1.4-1.6x longer), which is
+ * why it is off by default; it stays as a tested option.  Falls back to 0 by itself for short sequences, the sort-based entry pipeline, debug
+ * dumps, per-kernel timing and after a table overflow.  icm_get_pipeline_used: the last sweep. */
+int icm_set_pipeline(icm_handle *h, int on);
+int icm_get_pipeline_used(const icm_handle *h);
+
 /* How many times an even wave of the one-launch solve polls for its odd neighbours (~0.2 us per
  * poll; default 1 << 17) before it DEFERS: it leaves its poses untouched and the fix-up launch
  * queued right behind (k_solve_m_deferred) solves them after the kernel boundary.  Forward

@@ -679,3 +679,89 @@ def test_non_finite_inputs_do_not_hang():
         except (IndexError, ValueError, RuntimeError) as e:
             print(what, "-> raised", type(e).__name__, str(e)[:80])
         eng.close()
+
+
+def test_pipelined_sweep_is_bit_identical_and_recovers_from_overflow():
+    """The two-segment pipelined sweep (phase A/B of one time segment beside the solves of the other,
+    two HIP streams) against the one-stream sweep: S1 over 6 sweeps with state reads, snapshot /
+    restore and host-array sweeps in between -- every state bit-equal."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import WORKLOADS, make_workload
+    wl = make_workload(*WORKLOADS["S1"])
+    cfg = ConfigICM(D=wl.config)
+
+    def run(pipe):
+        eng = SweepEngine(cfg)
+        eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+        eng.set_pipeline(pipe)
+        eng.set_state(wl.map_init, wl.x_init, wl.x0)
+        out, used = [], []
+        for it in range(6):
+            eng.sweep_device("redblack")
+            used.append(eng.pipeline_used())
+            if it == 1:
+                eng.snapshot_state()
+            if it in (0, 2, 5):
+                out.append(eng.get_state())
+        eng.restore_state()                      # back to the state after sweep 2 ...
+        eng.sweep_device("redblack")             # ... and sweep 3 again
+        out.append(eng.get_state())
+        x = out[-1][0].copy()                    # a host-array sweep from there (icm_sweep: set_state + sweep + get_state)
+        mo, co, K = eng.sweep(out[-1][1][:, :out[-1][3]], x, wl.x0, out[-1][3], "redblack")
+        out.append((x, mo, co, K))
+        nd = eng.fused_deferred()
+        eng.close()
+        return out, used, nd
+
+    ref, used0, _ = run(False)
+    got, used1, nd = run(True)
+    assert not any(used0) and all(used1)
+    print("pipelined S1: even waves deferred %d" % nd)
+    for a, b in zip(ref, got):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    # restore + one sweep reproduces sweep 3 of the straight run
+    assert np.array_equal(got[3][0], got[1][0]) and np.array_equal(got[3][1], got[1][1])
+
+
+def test_pipelined_sweep_on_the_dataset_and_dense_map_fallback():
+    """data_IJAC2018 (1833 poses, 16-pose chunks) pipelined == unsegmented over three sweeps; a map so
+    dense that a scan overflows the per-pose table makes a pipelined sweep roll its first segment
+    back and finish on the unsegmented path, with the same result."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from util import Cfg, dataset, gold
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    res = []
+    for pipe in (False, True):
+        eng = SweepEngine(Cfg())
+        eng.upload(zz, odo, u)
+        eng.set_pipeline(pipe)
+        eng.set_state(init["map_init"], init["x_init"], odo[:, 0], int(init["landmarks_actuales"]))
+        for _ in range(3):
+            eng.sweep_device("redblack")
+        res.append((eng.get_state(), eng.pipeline_used()))
+        eng.close()
+    assert res[0][1] is False and res[1][1] is True
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    lm, scans, x_true, u2, cfgd = _dense_ring_case()
+    cfg = ConfigICM(D=cfgd)
+    rep = 400                                     # 2400 poses: long enough to be cut into two segments
+    scans_l, odo_l, u_l = np.tile(scans, (1, rep)), np.tile(x_true, (1, rep)), np.tile(u2, (1, rep))
+    res = []
+    for pipe in (False, True):
+        e = SweepEngine(cfg)
+        e.upload(scans_l, odo_l, u_l)
+        e.set_pipeline(pipe)
+        e.set_state(lm, odo_l.copy(), odo_l[:, 0])
+        e.sweep_device("redblack")
+        first = e.pipeline_used()
+        e.sweep_device("redblack")
+        res.append((e.get_state(), first, e.pipeline_used()))
+        e.close()
+    assert res[1][1] is False and res[1][2] is False     # the overflow sent it to the unsegmented path, for good
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)

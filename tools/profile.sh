@@ -1,12 +1,18 @@
+# rocprofv3 passes behind profiles/r02_*: run on the GPU box from the repo root,
+#   gpurun -- 'bash tools/profile.sh TAG'
+# kernel-trace/stats and the PMC passes are separate runs (the pool refuses them combined).
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python bench.py --workload S2 --steps 3 --warmup 1 --cpu-poses 0 --no-roofline"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v8 -- python bench.py --workload S2 --steps 10 --warmup 2 --cpu-poses 0 > gpurun_out/prof_v8.log 2>&1 && \
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc8a -- $B > gpurun_out/pmc8a.log 2>&1 && \
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc8f -- $B > gpurun_out/pmc8f.log 2>&1 && \
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc8w -- $B > gpurun_out/pmc8w.log 2>&1 && \
-python tools/pmc_summary.py gpurun_out/pmc8_summary.csv gpurun_out/pmc8a gpurun_out/pmc8f gpurun_out/pmc8w > /dev/null && \
-timeout -k 10 400 python bench.py > gpurun_out/bench_v8.log 2>&1 && \
-timeout -k 10 300 python bench.py --workload S1 --steps 20 --warmup 3 > gpurun_out/bench_s1_v8.log 2>&1
+B="python3 bench.py --workload S2 --steps 6 --warmup 2 --cpu-poses 0 --no-roofline --no-extras"
+O=gpurun_out/prof_$TAG
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --workload S2 --steps 20 --warmup 5 --cpu-poses 0 --no-extras > $O.stats.log 2>&1 && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_a -- $B > $O.pmc_a.log 2>&1 && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_b -- $B > $O.pmc_b.log 2>&1 && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- $B > $O.pmc_f.log 2>&1 && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- $B > $O.pmc_w.log 2>&1
 echo rc=$?
-tail -1 gpurun_out/bench_v8.log | cut -c1-600
-find gpurun_out/prof_v8 -name "*kernel_stats.csv" | head -1 | xargs head -20
+python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_busy_S2.csv $O/pmc_a $O/pmc_b > /dev/null
+python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_traffic_S2.csv $O/pmc_f $O/pmc_w > /dev/null
+find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${TAG}_S2_kernel_stats.csv
+tail -1 $O.stats.log | cut -c1-400
+head -25 gpurun_out/${TAG}_S2_kernel_stats.csv
