@@ -118,7 +118,7 @@ struct icm_handle {
         DevBuf<GridParams> gpar;
         std::vector<double> h_map, h_counts;
         int64_t K = 0, lact = 0;
-        bool h_map_valid = true, valid = false;
+        bool h_map_valid = true, valid = false, dev_map_current = false;
     } snap;
     DevBuf<int> solve_flags;  // fused red-black solve: [nw] completion flags of the odd waves | [nw] deferred marks of the even waves
     DevBuf<unsigned long long> solve_ndef;   // even waves that deferred to the fix-up launch, over the handle's life
@@ -142,7 +142,12 @@ struct icm_handle {
     int form = 0;  // 0 moments (lane per pose), 1 per beam, 2 per entry (wave per pose)
     int *pin_i = nullptr, *pin_i_dev = nullptr;   // pinned host words and their device-side address
     double* pin_d = nullptr;  // pinned staging: raw map download (3L)
+    DevBuf<double> pack;         // refined map + counters packed for one download
+    std::vector<double> h_pack;
+    DevBuf<double> x_rows;       // (3,T) staging of the caller's pose layout (transposed to / from (T,3) on the device)
+    bool dev_map_current = false;   // the device search structures hold exactly h_map (K, lact)
     std::vector<double> h_yraw, h_cntraw;
+    bool raw_on_device = false;   // y_raw / cnt_raw of the last sweep have not been copied to h_yraw / h_cntraw yet
 
     // timing
     bool timing = false;
@@ -301,6 +306,7 @@ int icm_destroy(icm_handle* h) {
     h->snap.g_cell.release(); h->snap.g_lm.release(); h->snap.g_nb.release(); h->snap.gpar.release();
     if (h->pin_i) (void)hipHostFree(h->pin_i);
     if (h->pin_d) (void)hipHostFree(h->pin_d);
+    h->x_rows.release(); h->pack.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_map) (void)hipEventDestroy(h->ev_map);
@@ -324,6 +330,24 @@ int icm_set_stream(icm_handle* h, void* s) {
     h->stream = reinterpret_cast<hipStream_t>(s);
     h->own_stream = false;
     return ICM_OK;
+}
+
+// The reference keeps poses as a (3,T) array (all x, all y, all theta); the kernels want one
+// (x, y, theta) row per pose.  The change of layout runs on the device, so the host side of a
+// drop-in call is one copy of the caller's array each way.
+__global__ __launch_bounds__(256) void k_x_rows_to_poses(const double* __restrict__ rows, double* __restrict__ x, int T) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    x[3 * (size_t)t] = rows[t];
+    x[3 * (size_t)t + 1] = rows[(size_t)T + t];
+    x[3 * (size_t)t + 2] = rows[2 * (size_t)T + t];
+}
+__global__ __launch_bounds__(256) void k_x_poses_to_rows(const double* __restrict__ x, double* __restrict__ rows, int T) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    rows[t] = x[3 * (size_t)t];
+    rows[(size_t)T + t] = x[3 * (size_t)t + 1];
+    rows[2 * (size_t)T + t] = x[3 * (size_t)t + 2];
 }
 
 // The solves of a pipelined sweep run on solve_stream.  Everything else in this library orders
@@ -437,6 +461,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         const size_t nrec = (size_t)h->nchunks * kT1;
         HIPCHK(h, h->rec_label.reserve(nrec)); HIPCHK(h, h->rec_s.reserve(3 * nrec)); HIPCHK(h, h->rec_off.reserve(3 * nrec));
         HIPCHK(h, h->ms.reserve(3 * (size_t)h->nsuper * L));
+        h->ms_clean = false;
     }
     size_t tmp_bytes = 0;
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, nz, 0, 32, h->stream));
@@ -488,10 +513,13 @@ static int upload_map(icm_handle* h) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors are reused
     h->h_map_valid = true;
+    h->dev_map_current = true;
     return ICM_OK;
 }
 
-int icm_set_state(icm_handle* h, const double* x, const double* x0, const double* map_in, int64_t K, int64_t lact_in) {
+// wait_host: the caller's arrays may be reused as soon as this returns (the public entry point);
+// icm_sweep keeps them for the whole call and lets the copies run behind the queue.
+static int set_state_impl(icm_handle* h, const double* x, const double* x0, const double* map_in, int64_t K, int64_t lact_in, bool wait_host) {
     if (!h) return ICM_ERR_ARG;
     if (!h->prefiltered) FAIL(h, ICM_ERR_ARG, "icm_set_state: call icm_upload + icm_prefilter first");
     if (!x || !x0 || (K > 0 && !map_in)) FAIL(h, ICM_ERR_ARG, "icm_set_state: null pointer");
@@ -507,24 +535,34 @@ int icm_set_state(icm_handle* h, const double* x, const double* x0, const double
         h->x = h->x_own.p;
     }
     HIPCHK(h, h->x0.reserve(3));
-    std::vector<double> xt(3 * T);
-    for (size_t t = 0; t < T; ++t) {
-        xt[3 * t] = x[t];
-        xt[3 * t + 1] = x[T + t];
-        xt[3 * t + 2] = x[2 * T + t];
-    }
-    HIPCHK(h, hipMemcpyAsync(h->x, xt.data(), 3 * T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, h->x_rows.reserve(3 * T));
+    HIPCHK(h, hipMemcpyAsync(h->x_rows.p, x, 3 * T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    k_x_rows_to_poses<<<(int)((T + 255) / 256), 256, 0, h->stream>>>(h->x_rows.p, h->x, (int)T);
     HIPCHK(h, hipMemcpyAsync(h->x0.p, x0, 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->h_map.assign(map_in, map_in + 2 * K);
-    h->K = K;
-    h->lact = lact_in;
-    int rc = upload_map(h);
-    if (rc) return rc;
+    HIPCHK(h, hipGetLastError());
+    // The driver loop hands back the map the previous sweep returned (mapa_viejo = copy(mapa_refinado),
+    // scripts/ICM_ROS.py:311): if these are exactly the values the device structures were built from,
+    // the search grid of the last Mapa.filtrar is reused instead of being rebuilt and uploaded.
+    const bool same_map = h->dev_map_current && h->h_map_valid && K == h->K && lact_in == h->lact &&
+                          h->h_map.size() == 2 * (size_t)K &&
+                          (K == 0 || std::memcmp(map_in, h->h_map.data(), 2 * (size_t)K * sizeof(double)) == 0);
+    if (!same_map) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->h_map.assign(map_in, map_in + 2 * K);
+        h->K = K;
+        h->lact = lact_in;
+        int rc = upload_map(h);
+        if (rc) return rc;
+    }
     h->have_state = true;
     h->hier_ok = true;
     h->pipe_ok = true;
+    if (wait_host) HIPCHK(h, hipStreamSynchronize(h->stream));
     return ICM_OK;
+}
+
+int icm_set_state(icm_handle* h, const double* x, const double* x0, const double* map_in, int64_t K, int64_t lact_in) {
+    return set_state_impl(h, x, x0, map_in, K, lact_in, true);
 }
 
 int64_t icm_stats_stride(const icm_handle* h) { return h ? 3 * h->cfg.L + 8 : 0; }
@@ -859,8 +897,6 @@ int icm_sweep_targets(icm_handle* h) {
     HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
     const size_t Ls = (size_t)L;
-    HIPCHK(h, hipMemcpyAsync(h->pin_d, h->y_raw.p, 2 * Ls * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
-    HIPCHK(h, hipMemcpyAsync(h->pin_d + 2 * Ls, h->cnt_raw.p, Ls * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
     if (h->world > 1)
         for (int r = 0; r < h->world && r < 64; ++r)
             HIPCHK(h, hipMemcpyAsync(h->pin_d + 3 * Ls + 16 + r, h->stats_all + (size_t)r * (size_t)icm_stats_stride(h) + 3 * Ls, sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
@@ -967,6 +1003,18 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     return ICM_OK;
 }
 
+// Raw running map and counters of the last sweep (before Mapa.filtrar) -> host, on demand.
+static int fetch_raw_map(icm_handle* h) {
+    if (!h->raw_on_device) return ICM_OK;
+    const size_t L = (size_t)h->cfg.L;
+    h->h_yraw.resize(2 * L);
+    h->h_cntraw.resize(L);
+    HIPCHK(h, hipMemcpy(h->h_yraw.data(), h->y_raw.p, 2 * L * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(h->h_cntraw.data(), h->cnt_raw.p, L * sizeof(double), hipMemcpyDeviceToHost));
+    h->raw_on_device = false;
+    return ICM_OK;
+}
+
 int icm_sweep_finish(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_finish: no state");
@@ -988,8 +1036,7 @@ int icm_sweep_finish(icm_handle* h) {
     }
     h->lact_raw = h->lact0 + n_new;
     if (h->lact_raw > (int64_t)L) FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L");
-    h->h_yraw.assign(h->pin_d, h->pin_d + 2 * L);
-    h->h_cntraw.assign(h->pin_d + 2 * L, h->pin_d + 3 * L);
+    h->raw_on_device = true;   // (raw map and counters stay in y_raw / cnt_raw until somebody asks: fetch_raw_map)
     h->filtrar_path = 2;
     if (h->gpu_filtrar && h->pin_i[9] == 1) {
         // survivors closer than dist_thr: merged on the device (rare; one extra round trip)
@@ -1005,7 +1052,8 @@ int icm_sweep_finish(icm_handle* h) {
         // Mapa.filtrar and the search grid of the refined map were produced on the GPU
         // (k_filtrar_grid); the refined map becomes the next mapa_viejo (scripts/ICM_ROS.py:311)
         h->K = h->lact = h->pin_i[8];
-        h->h_map_valid = false;
+        h->dev_map_current = true;
+        h->h_map_valid = false;   // fetched when asked for (sync_host_map)
         // No wait for the solves here: everything the host needs (raw map, filtrar result) came
         // over the side stream, and whatever is queued next on the main stream is ordered behind
         // them -- the next sweep's phase A starts the moment the last solve ends.  (Readers of x
@@ -1014,6 +1062,10 @@ int icm_sweep_finish(icm_handle* h) {
         return ICM_OK;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    {
+        int rcf = fetch_raw_map(h);
+        if (rcf) return rcf;
+    }
     std::vector<double> yo(2 * L), co(L);
     int64_t lact_new = 0;
     int rc = filtrar_host(h->cfg, h->h_yraw.data(), h->h_cntraw.data(), h->lact_raw, yo.data(), co.data(), &lact_new, h->err);
@@ -1035,11 +1087,19 @@ static int sync_host_map(icm_handle* h) {
     const size_t K = (size_t)h->K, L = (size_t)h->cfg.L;
     h->h_map.assign(2 * K, 0.0);
     h->h_counts.assign(L, 0.0);
+    // the refined map's K columns and the counters, packed on the device into ONE download
+    HIPCHK(h, h->pack.reserve(2 * L + L));
     if (K) {
-        HIPCHK(h, hipMemcpy(h->h_map.data(), h->mapx.p, K * sizeof(double), hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(h->h_map.data() + K, h->mapy.p, K * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpyAsync(h->pack.p, h->mapx.p, K * sizeof(double), hipMemcpyDeviceToDevice, h->copy_stream));
+        HIPCHK(h, hipMemcpyAsync(h->pack.p + K, h->mapy.p, K * sizeof(double), hipMemcpyDeviceToDevice, h->copy_stream));
     }
-    HIPCHK(h, hipMemcpy(h->h_counts.data(), h->counts_new.p, L * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpyAsync(h->pack.p + 2 * K, h->counts_new.p, L * sizeof(double), hipMemcpyDeviceToDevice, h->copy_stream));
+    std::vector<double>& st = h->h_pack;
+    st.resize(2 * K + L);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->pack.p, (2 * K + L) * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    std::copy(st.begin(), st.begin() + 2 * K, h->h_map.begin());
+    std::copy(st.begin() + 2 * K, st.end(), h->h_counts.begin());
     h->h_map_valid = true;
     return ICM_OK;
 }
@@ -1067,7 +1127,7 @@ int icm_snapshot_state(icm_handle* h) {
     HIPCHK(h, hipMemcpyAsync(sn.gpar.p, h->gpar.p, sizeof(GridParams), hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipStreamSynchronize(st));
     sn.h_map = h->h_map; sn.h_counts = h->h_counts;
-    sn.K = h->K; sn.lact = h->lact; sn.h_map_valid = h->h_map_valid;
+    sn.K = h->K; sn.lact = h->lact; sn.h_map_valid = h->h_map_valid; sn.dev_map_current = h->dev_map_current;
     sn.valid = true;
     return ICM_OK;
 }
@@ -1089,7 +1149,7 @@ int icm_restore_state(icm_handle* h) {
     HIPCHK(h, hipMemcpyAsync(h->g_nb.p, sn.g_nb.p, nc * sizeof(NeighRec), hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->gpar.p, sn.gpar.p, sizeof(GridParams), hipMemcpyDeviceToDevice, st));
     h->h_map = sn.h_map; h->h_counts = sn.h_counts;
-    h->K = sn.K; h->lact = sn.lact; h->h_map_valid = sn.h_map_valid;
+    h->K = sn.K; h->lact = sn.lact; h->h_map_valid = sn.h_map_valid; h->dev_map_current = sn.dev_map_current;
     return ICM_OK;
 }
 
@@ -1236,15 +1296,12 @@ static int icm_sweep_pipelined(icm_handle* h) {
     HIPCHK(h, hipEventRecord(h->ev_s[1], Y));
     h->solves_in_flight = true;
     // raw map download, the four counters, Mapa.filtrar + search grid: copy stream, beside moments / solves
-    const size_t Ls = (size_t)L;
     HIPCHK(h, hipStreamWaitEvent(Cs, h->ev_map, 0));
     {
         int rc = launch_filtrar(h, Cs, true);   // (first: the next sweep's phase A waits for the new map, not for the downloads)
         if (rc) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(h->pin_i, h->flags.p + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, Cs));
-    HIPCHK(h, hipMemcpyAsync(h->pin_d, h->y_raw.p, 2 * Ls * sizeof(double), hipMemcpyDeviceToHost, Cs));
-    HIPCHK(h, hipMemcpyAsync(h->pin_d + 2 * Ls, h->cnt_raw.p, Ls * sizeof(double), hipMemcpyDeviceToHost, Cs));
     HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, Cs));
     HIPCHK(h, hipEventRecord(h->ev_copied, Cs));
     h->map_copy_pending = true;
@@ -1301,14 +1358,11 @@ int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out,
     }
     const size_t T = (size_t)h->T, L = (size_t)h->cfg.L;
     if (x) {
-        std::vector<double> xt(3 * T);
-        HIPCHK(h, hipMemcpyAsync(xt.data(), h->x, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, h->x_rows.reserve(3 * T));
+        k_x_poses_to_rows<<<(int)((T + 255) / 256), 256, 0, h->stream>>>(h->x, h->x_rows.p, (int)T);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(x, h->x_rows.p, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        for (size_t t = 0; t < T; ++t) {
-            x[t] = xt[3 * t];
-            x[T + t] = xt[3 * t + 1];
-            x[2 * T + t] = xt[3 * t + 2];
-        }
     }
     if (map_out) {
         std::fill(map_out, map_out + 2 * L, 0.0);
@@ -1325,7 +1379,7 @@ int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out,
 int icm_sweep(icm_handle* h, double* x, const double* x0, const double* map_in, int64_t K, int64_t lact_in,
               int schedule, double* map_out, double* counts_out, int64_t* K_out) {
     int rc;
-    if ((rc = icm_set_state(h, x, x0, map_in, K, lact_in))) return rc;
+    if ((rc = set_state_impl(h, x, x0, map_in, K, lact_in, false))) return rc;
     if ((rc = icm_sweep_device(h, schedule))) return rc;
     if (h->scan0_empty) {
         if (K_out) *K_out = -1;
@@ -1358,7 +1412,12 @@ int icm_get_association(icm_handle* h, int32_t* labels, double* target_x, double
 
 int icm_get_raw_map(icm_handle* h, double* y, double* counts, int64_t* lact) {
     if (!h) return ICM_ERR_ARG;
-    if (h->h_yraw.empty()) FAIL(h, ICM_ERR_ARG, "icm_get_raw_map: no sweep has finished");
+    if (h->h_yraw.empty() && !h->raw_on_device) FAIL(h, ICM_ERR_ARG, "icm_get_raw_map: no sweep has finished");
+    {
+        HIPCHK(h, hipSetDevice(h->device));
+        int rcf = fetch_raw_map(h);
+        if (rcf) return rcf;
+    }
     if (y) std::copy(h->h_yraw.begin(), h->h_yraw.end(), y);
     if (counts) std::copy(h->h_cntraw.begin(), h->h_cntraw.end(), counts);
     if (lact) *lact = h->lact_raw;
@@ -1476,6 +1535,7 @@ int icm_filtrar_device(icm_handle* h, const double* y, const double* counts, int
     }
     h->lact0 = lact0_keep;
     h->have_state = false;   // the search structures now belong to this map, not to the sweep state
+    h->dev_map_current = false;
     if (rc) return rc;
     if (info[1] == 2) {      // coincident landmarks / empty map / a component beyond kCompMax: exact host routine
         if (path_out) *path_out = 2;

@@ -765,3 +765,37 @@ def test_pipelined_sweep_on_the_dataset_and_dense_map_fallback():
     assert res[1][1] is False and res[1][2] is False     # the overflow sent it to the unsegmented path, for good
     for a, b in zip(res[0][0], res[1][0]):
         assert np.array_equal(a, b)
+
+
+def test_host_array_sweeps_reuse_the_device_map_only_when_it_is_the_same_map():
+    """icm_sweep keeps the search grid of the last Mapa.filtrar when the caller hands back exactly the
+    map it returned (the reference driver's mapa_viejo = copy(mapa_refinado)); any edit of the map --
+    here one landmark moved out of reach of its beams -- must reach the device."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    wl = make_workload(1900, 100, 180)
+    cfg = ConfigICM(D=wl.config)
+
+    def two_sweeps(edit, fresh_engine_for_second):
+        eng = SweepEngine(cfg)
+        eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+        x = wl.x_init.copy()
+        mo, co, K = eng.sweep(wl.map_init, x, wl.x0, wl.K, "redblack")
+        mv = mo[:, :K].copy()
+        if edit:
+            mv[0, 3] += 5.0
+        if fresh_engine_for_second:
+            eng.close()
+            eng = SweepEngine(cfg)
+            eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+        mo2, co2, K2 = eng.sweep(mv, x, wl.x0, K, "redblack")
+        eng.close()
+        return x, mo2[:, :K2], co2
+
+    for edit in (False, True):
+        a = two_sweeps(edit, False)
+        b = two_sweeps(edit, True)
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    assert not np.array_equal(two_sweeps(False, False)[1], two_sweeps(True, False)[1])
