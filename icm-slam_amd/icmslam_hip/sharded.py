@@ -97,6 +97,10 @@ class ShardedSweep:
         e.sweep_local()
         self.comm.gather_stats(self)
         e.sweep_targets()
+        if self.world == 1:        # no neighbour, no halo: both colours in the one-launch solve
+            e.sweep_solve("redblack", -1)
+            e.sweep_finish()
+            return
         e.sweep_solve("redblack", 1)
         self.comm.halo(self)
         e.sweep_solve("redblack", 0)
