@@ -1,6 +1,6 @@
 // C-ABI of the MI355X-native ICM sweep (include/icmslam.h): handle, HBM buffers, sweep
 // orchestration.  Device work goes to one HIP stream, plus a side stream for the fused map
-// filter (k_filtrar_grid) and the asynchronous raw-map download, both overlapped with the pose
+// filter (the k_fl_* chain), overlapped with the pose
 // solves.  Host round trips per sweep: one 12-byte read-back (entry / new-landmark counts --
 // rocPRIM needs the sort size) and one 16-byte read-back of the filter result; Mapa.filtrar
 // falls back to the host routine only when landmarks have to be merged.
@@ -1050,7 +1050,7 @@ int icm_sweep_finish(icm_handle* h) {
     }
     if (h->gpu_filtrar && h->pin_i[9] == 0) {
         // Mapa.filtrar and the search grid of the refined map were produced on the GPU
-        // (k_filtrar_grid); the refined map becomes the next mapa_viejo (scripts/ICM_ROS.py:311)
+        // (k_fl_* chain); the refined map becomes the next mapa_viejo (scripts/ICM_ROS.py:311)
         h->K = h->lact = h->pin_i[8];
         h->dev_map_current = true;
         h->h_map_valid = false;   // fetched when asked for (sync_host_map)

@@ -18,8 +18,8 @@
 //             k_lm_scan        one wave per landmark: time-ordered prefix of its entries
 //                              -> running-mean target of every entry, landmark totals
 //             k_stats_prefix   totals + exclusive prefix over lower ranks (after all-gather)
-//             k_filtrar_grid   Mapa.filtrar + search grid of the refined map (one workgroup,
-//                              side stream, under the solves)
+//             k_fl_*           Mapa.filtrar + search grid of the refined map (multi-workgroup chain,
+//                              side stream, under the solves; merges on the device)
 //   phase C   k_pose_moments[_h]  14 moment sums of the pose's observation energy
 //             k_solve_m_*      Nelder-Mead on the conditional energy in moment form:
 //                              ONE LANE per pose, everything in registers
@@ -303,7 +303,7 @@ struct LmRec {      // one landmark of the cell-sorted table (32 B: one aligned 
     int id, pad0, pad1, pad2;
 };
 
-struct GridParams {  // device resident: written by the host (icm_set_state) or by k_filtrar_grid
+struct GridParams {  // device resident: written by the host (icm_set_state) or by the k_fl_* chain
     double gx0, gy0, inv;
     int nx, ny;
 };

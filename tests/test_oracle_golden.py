@@ -179,3 +179,29 @@ def test_c_oracle_equals_numpy_oracle_redblack(cfg, kept):
     xn = np.ascontiguousarray(init["x_init"][:, :T]).copy()
     mn, xn = o.sweep(c2, st, zz[:, :T], u[:, :T], odo[:, :T], odo[:, 0], init["map_init"].copy(), xn, schedule="redblack", kept=kept[:T])
     assert Kc == mn.shape[1] and np.abs(mc - mn).max() <= 1e-12 and np.abs(xc - xn).max() <= 1e-9
+
+
+def test_c_oracle_grid_association_and_threads_do_not_change_anything():
+    """The C oracle's two accelerations are exact: the grid-accelerated association returns the
+    brute-force cdist/argmin answer (labels, targets, map, poses bit-equal), and the OpenMP thread
+    count does not enter the result."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip.synthetic import make_workload
+    from oracle import c_oracle as co
+    wl = make_workload(1400, 400, 360)
+    cfg_s = ConfigICM(D=wl.config)
+    kept = co.prefilter(cfg_s, wl.scans.T)
+    res = []
+    for grid, threads in ((False, 1), (True, 1), (True, 0)):
+        co.set_grid(grid)
+        co.set_threads(threads)
+        x = wl.x_init.copy()
+        a = {}
+        mv, cnt, K, raw = co.sweep(cfg_s, kept, wl.u, wl.odometry, wl.x0, wl.map_init, x, wl.K, "redblack", assoc=a)
+        res.append((x, mv, cnt, a["labels"].copy(), a["targets"].copy(), raw[0], raw[1]))
+    co.set_grid(True)
+    co.set_threads(0)
+    assert (res[0][3] >= 0).all() and len(set(res[0][3])) > 100      # the case really associates against many landmarks
+    for other in res[1:]:
+        for u, v in zip(res[0], other):
+            assert np.array_equal(u, v)
