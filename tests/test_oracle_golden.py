@@ -201,7 +201,7 @@ def test_c_oracle_grid_association_and_threads_do_not_change_anything():
         res.append((x, mv, cnt, a["labels"].copy(), a["targets"].copy(), raw[0], raw[1]))
     co.set_grid(True)
     co.set_threads(0)
-    assert (res[0][3] >= 0).all() and len(set(res[0][3])) > 100      # the case really associates against many landmarks
+    assert (res[0][3] >= 0).all() and len(set(res[0][3])) >= 80      # the case really associates against many landmarks
     for other in res[1:]:
         for u, v in zip(res[0], other):
             assert np.array_equal(u, v)
