@@ -80,6 +80,7 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True):
         # both colours together, per pose: 17 moments, own + 2 neighbour poses, odometry 72, u 32, pose out 24
         "k_solve": nloc * (136 + 72 + 72 + 32 + 24 + 8),
         "k_scan": nloc * 16,
+        "k_pose_rot": nloc * (24 + 16),
     }
     return per_sweep.get(kernel, 0) / max(nlaunch, 1)
 

@@ -28,12 +28,12 @@ std::string g_create_err;
 
 enum KernelId {
     KID_PREFILTER = 0, KID_SCAN, KID_ASSOC_BRUTE, KID_ASSOC_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_TOTALS,
-    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_SOLVE_DEFERRED, KID_FILTRAR, KID_NEIGH, KID_CHUNK_L1, KID_CHUNK_L2, KID_LM_L3, KID_REC_PUSH, KID_COUNT
+    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_SOLVE_DEFERRED, KID_FILTRAR, KID_NEIGH, KID_CHUNK_L1, KID_CHUNK_L2, KID_LM_L3, KID_REC_PUSH, KID_POSE_ROT, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_scan", "k_associate_brute", "k_assoc_group", "k_compact",
                                        "radix_sort_pairs", "k_lm_bounds", "k_lm_scan_totals", "k_stats_prefix",
                                        "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_solve_deferred", "k_filtrar", "k_neigh_table",
-                                       "k_chunk_l1", "k_chunk_l2", "k_lm_l3", "k_rec_push"};
+                                       "k_chunk_l1", "k_chunk_l2", "k_lm_l3", "k_rec_push", "k_pose_rot"};
 
 template <class T>
 struct DevBuf {
@@ -166,6 +166,7 @@ struct icm_handle {
     bool pipe_ok = true;             // cleared by a table overflow until the next icm_set_state
     int pipe_used = 0;               // the last sweep ran pipelined
     DevBuf<double> x_bak, l3_carry;
+    DevBuf<double> rot;   // (cos, sin)(theta - pi/2) per pose of the shard, refreshed at the start of every sweep (k_pose_rot)
     DevBuf<int> scan_carry;
     hipEvent_t ev_map = nullptr, ev_copied = nullptr;
     bool map_copy_pending = false;
@@ -314,7 +315,7 @@ int icm_destroy(icm_handle* h) {
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->solve_stream) { (void)hipStreamSynchronize(h->solve_stream); (void)hipStreamDestroy(h->solve_stream); }
     for (int q = 0; q < 2; ++q) { if (h->ev_m[q]) (void)hipEventDestroy(h->ev_m[q]); if (h->ev_s[q]) (void)hipEventDestroy(h->ev_s[q]); }
-    h->x_bak.release(); h->l3_carry.release(); h->scan_carry.release();
+    h->x_bak.release(); h->l3_carry.release(); h->scan_carry.release(); h->rot.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ICM_OK;
@@ -433,6 +434,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->pose_s2.reserve(3 * (size_t)nloc));
     HIPCHK(h, h->pose_c.reserve(3 * (size_t)nloc));
     HIPCHK(h, h->pose_m.reserve(17 * (size_t)nloc));
+    HIPCHK(h, h->rot.reserve(2 * (size_t)nloc));
     TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p)));
     // per-sweep buffers sized by the kept beams
     HIPCHK(h, h->label.reserve(nz)); HIPCHK(h, h->bloc.reserve(nz)); HIPCHK(h, h->st_label.reserve(nz));
@@ -759,8 +761,9 @@ int icm_sweep_local(icm_handle* h) {
 #define ASSOC_GROUP(PRE, DBG, HS)                                                                                  \
     TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS><<<nbw, kBlock, 0, h->stream>>>(                         \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
-        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p)))
+        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p)))
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
+    TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p)));
     if (h->brute)
         TIMED(h, KID_ASSOC_BRUTE, (k_associate_brute<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->mapx.p, h->mapy.p, km, h->cfg.dist_thr, h->label.p)));
     const int ntiles = (nloc + kScanTile - 1) / kScanTile;
@@ -880,7 +883,7 @@ int icm_sweep_targets(icm_handle* h) {
         TIMED(h, KID_POSE_MOMENTS, (k_pose_moments_h<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(
             h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p,
             pre, pre + nzs, reinterpret_cast<const unsigned*>(pre + 2 * nzs), reinterpret_cast<const unsigned char*>(h->e_val.p), h->chunk_poses,
-            ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr)));
+            ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr, 0, -1, h->rot.p)));
     } else if (h->world > 1) {
         TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
         TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, h->off_sx.p, h->off_sy.p, h->off_n.p, h->tgt.p, nullptr, nullptr, nullptr)));
@@ -1247,10 +1250,11 @@ static int icm_sweep_pipelined(icm_handle* h) {
         if (h->solves_in_flight) HIPCHK(h, hipStreamWaitEvent(X, h->ev_s[seg], 0));
         if (seg == 0) HIPCHK(h, hipMemcpyAsync(h->x_bak.p, h->x, 3 * (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, X));
         const int nbw = nblocks_waves(nseg);
+        k_pose_rot<<<nblocks_threads(nseg), kBlock, 0, X>>>(h->x, h->x0.p, t0, nseg, h->rot.p + 2 * (size_t)t0);
 #define ASSOC_SEG(HS)                                                                                                 \
     k_assoc_group<false, false, HS><<<nbw, kBlock, 0, X>>>(h->x, h->x0.p, t0, nseg, h->boff.p + t0, h->bx.p, h->by.p, gv,  \
         h->cfg.dist_thr, h->thr2, h->label.p, h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p + t0, \
-        h->isnew.p + t0, h->flags.p)
+        h->isnew.p + t0, h->flags.p, h->rot.p + 2 * (size_t)t0)
         if (h->hash_slots == 128) ASSOC_SEG(128); else ASSOC_SEG(256);
 #undef ASSOC_SEG
         const int ntiles = (nseg + kScanTile - 1) / kScanTile;
@@ -1275,7 +1279,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
         k_pose_moments_h<<<nblocks_threads((int64_t)nseg * 16), kBlock, 0, X>>>(
             h->x, h->x0.p, 0, nloc, h->boff.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, pre, pre + nzs,
             reinterpret_cast<const unsigned*>(pre + 2 * nzs), reinterpret_cast<const unsigned char*>(h->e_val.p), CH, ro, ro + nrec,
-            ro + 2 * (size_t)nrec, h->pose_m.p, nullptr, t0, t1);
+            ro + 2 * (size_t)nrec, h->pose_m.p, nullptr, t0, t1, h->rot.p);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipEventRecord(h->ev_m[seg], X));
         if (seg == 0) {   // its solves start beside the second segment's phase A/B

@@ -37,11 +37,19 @@ __device__ __forceinline__ double bcast_first(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// DPP move of a double (two dwords); lanes without a source read 0.
+// DPP move of a double (two dwords); lanes without a source read 0.  With every row enabled the
+// zero comes from bound_ctrl (no destination to preset: saves a v_mov per dword); with masked rows
+// (row_bcast into rows 1/3 or 2/3) the disabled rows keep the preset 0.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    int lo, hi;
+    if constexpr (ROW_MASK == 0xF) {
+        lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    }
     return __hiloint2double(hi, lo);
 }
 

@@ -356,6 +356,20 @@ __device__ __forceinline__ void pose_rot(double th, double& ct, double& st) {
     st = s_;
 }
 
+// (cos, sin)(theta - pi/2) of every pose of the shard, once per sweep: phase A and the moment kernel
+// read them instead of every wavefront re-deriving its pose's pair (a generic FP64 sincos is ~150
+// vector instructions, 15 % of a k_assoc_group wave).  rot[2 tl], rot[2 tl + 1].
+__global__ __launch_bounds__(kBlock) void k_pose_rot(const double* __restrict__ x, const double* __restrict__ x0, int t_begin,
+                                                     int nloc, double* __restrict__ rot) {
+    const int tl = blockIdx.x * kBlock + threadIdx.x;
+    if (tl >= nloc) return;
+    double px, py, th, ct, st;
+    pose_of(x, x0, t_begin + tl, px, py, th);
+    pose_rot(th, ct, st);
+    rot[2 * (size_t)tl] = ct;
+    rot[2 * (size_t)tl + 1] = st;
+}
+
 // Gated nearest landmark of the world point (wx, wy).  The three cell rows around the point
 // are three contiguous ranges of the cell-sorted table; they are walked as ONE loop so the
 // wave iterates max-over-lanes of the candidate COUNT (about 1.5 on average), not three
@@ -635,7 +649,8 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int* __restrict__ bloc, int* __restrict__ st_label,
                                                         int* __restrict__ st_k, double* __restrict__ st_sbx,
                                                         double* __restrict__ st_sby, int* __restrict__ nent_out,
-                                                        int* __restrict__ isnew_out, int* __restrict__ flags) {
+                                                        int* __restrict__ isnew_out, int* __restrict__ flags,
+                                                        const double* __restrict__ rot = nullptr) {
     constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
     constexpr int kHashShift = HS == 128 ? 25 : 24;
     __shared__ PoseTable<HS> tables[kWavesPerBlock];
@@ -660,7 +675,12 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     double px, py, th;
     pose_of(x, x0, t_begin + tl, px, py, th);
     double ct, st;
-    pose_rot(th, ct, st);
+    if (rot) {   // (cos, sin)(theta - pi/2) from the sweep's table (k_pose_rot): the same values, computed once
+        ct = rot[2 * (size_t)tl];
+        st = rot[2 * (size_t)tl + 1];
+    } else {
+        pose_rot(th, ct, st);
+    }
     const GridParams gp = *g.par;
     int nent = 0;
     bool overflow = false;
@@ -699,7 +719,7 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         if (__ballot(dist >= 8) != 0ull) seg_step<0x118, 0xF>(dist >= 8, ax, ay);   // (wave-uniform skip)
         seg_step<0x142, 0xA>(dist > (lane & 15), ax, ay);   // run began in an earlier row
         seg_step<0x143, 0xC>(dist > (lane & 31), ax, ay);   // run began in rows 0-1
-        const int nexthead = __shfl_down(head ? 1 : 0, 1, kWave);
+        const int nexthead = dpp_mov_i<0x130, 0xF>(head ? 1 : 0);   // wave_shl:1 (lane 63 reads 0): no LDS round trip
         bool tail = valid && (lane == cn - 1 || nexthead);
         // run tails claim / find the slot of their label
         int slot = 0;
@@ -1993,7 +2013,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
                                                            const unsigned* __restrict__ pre_n, const unsigned char* __restrict__ e_rec, int chunk_poses,
                                                            const double* __restrict__ off_x, const double* __restrict__ off_y,
                                                            const double* __restrict__ off_n, double* __restrict__ pose_m,
-                                                           double2* __restrict__ tgt_out, int tl_begin = 0, int tl_end = -1) {
+                                                           double2* __restrict__ tgt_out, int tl_begin = 0, int tl_end = -1,
+                                                           const double* __restrict__ rot = nullptr) {
     const int sub = threadIdx.x & 15;
     const int tl = tl_begin + ((blockIdx.x * kBlock + threadIdx.x) >> 4);   // poses [tl_begin, tl_end)
     const bool live = tl < (tl_end < 0 ? nloc : tl_end);
@@ -2006,7 +2027,12 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
         n = nent[tl];
     }
     double ct, st;
-    pose_rot(th, ct, st);
+    if (rot) {
+        ct = live ? rot[2 * (size_t)tl] : 1.0;
+        st = live ? rot[2 * (size_t)tl + 1] : 0.0;
+    } else {
+        pose_rot(th, ct, st);
+    }
     double m[kMomentCount];
 #pragma unroll
     for (int q = 0; q < kMomentCount; ++q) m[q] = 0.0;
