@@ -197,8 +197,11 @@ class Job:
             eng.upload(wl.scans, wl.odometry, wl.u, t_begin=self.t_begin, t_end=self.t_end, pose_major=True)
         self.t_upload = time.perf_counter() - t0
         if sharded:
-            from icmslam_hip.sharded import ShardedSweep
-            self.runner = ShardedSweep(eng, rank, world, T)
+            from icmslam_hip.sharded import LibrarySweep, ShardedSweep
+            if args.collectives == "library" and factory is None:
+                self.runner = LibrarySweep(eng, rank, world, T)      # RCCL all-gathers issued by the C library
+            else:
+                self.runner = ShardedSweep(eng, rank, world, T)      # torch.distributed all_gather_into_tensor
             self.runner.set_state(wl.map_init, wl.x_init, wl.x0)
             self.inner = lambda: self.runner.sweep("redblack")
         else:
@@ -250,8 +253,55 @@ class Job:
         return elapsed
 
     def close(self):
+        if hasattr(getattr(self, "runner", None), "close"):
+            self.runner.close()
         if hasattr(self.eng, "close"):
             self.eng.close()
+
+
+def choose_collectives(args, rank, world, local_rank, dist):
+    """Who issues the two all-gathers of a sharded sweep.  "library": the C library itself (RCCL on the
+    handle's stream, one C call per sweep) -- taken when every rank resolves an RCCL library AND three
+    sweeps of the `tiny` workload give bit for bit the state the torch.distributed path gives;
+    otherwise "torch" (all_gather_into_tensor from Python).  Both are the product path."""
+    import numpy as np
+    import torch
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import LibrarySweep, ShardedSweep, partition
+    from icmslam_hip.synthetic import WORKLOADS, make_workload
+
+    def agree(flag):
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=args.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    probe = SweepEngine(ConfigICM(D=make_workload(*WORKLOADS["tiny"]).config), local_rank)
+    ok = agree(probe.comm_available())
+    probe.close()
+    if not ok:
+        return "torch", "no RCCL library resolved on some rank"
+    wl = make_workload(*WORKLOADS["tiny"])
+    cfg = ConfigICM(D=dict(wl.config, schedule="redblack"))
+    _, parts = partition(wl.T, world)
+    a, b = parts[rank]
+    states = []
+    for kind in (LibrarySweep, ShardedSweep):
+        eng = SweepEngine(cfg, local_rank)
+        eng.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
+        run = kind(eng, rank, world, wl.T)
+        run.set_state(wl.map_init, wl.x_init, wl.x0)
+        for _ in range(3):
+            run.sweep("redblack")
+        x, m, c, K = run.get_state()
+        states.append((x, m, c, K))
+        if hasattr(run, "close"):
+            run.close()
+        eng.close()
+    same = states[0][3] == states[1][3] and all(np.array_equal(p, q) for p, q in zip(states[0][:3], states[1][:3]))
+    if agree(same):
+        return "library", "validated against the torch.distributed path on the tiny workload (3 sweeps, bit-identical)"
+    return "torch", "library collectives disagreed with torch.distributed on the tiny workload"
 
 
 def roofline(job, ms_per_step):
@@ -370,7 +420,13 @@ def run_rank(args):
         factory = getattr(importlib.import_module(mod), fn)
     dist = None
     sharded = world > 1 or args.force_sharded
+    json_fd = None
     if sharded:
+        # RCCL prints a version banner on file descriptor 1 when a communicator is made: keep this
+        # rank's stdout for the ONE JSON line, everything else goes to stderr
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:  # plain `python bench.py --force-sharded`
@@ -388,6 +444,9 @@ def run_rank(args):
         ranks_seen = int(one.item())
         assert ranks_seen == dist.get_world_size() == world
 
+    collectives_note = None
+    if sharded and factory is None and args.collectives == "auto":
+        args.collectives, collectives_note = choose_collectives(args, rank, world, local_rank, dist)
     T1, K, B = WORKLOADS[args.workload]
     modes = [args.scaling] if world == 1 else [args.scaling, "weak" if args.scaling == "strong" else "strong"]
     records = {}
@@ -425,7 +484,10 @@ def run_rank(args):
                    "segments_pipelined": bool(job.eng.pipeline_used()) if hasattr(job.eng, "pipeline_used") else None,
                    "state_rewind": ("initial state restored on the device every %d sweeps" % RESET_EVERY) if job.rewind
                    else "none: %d consecutive sweeps from the initial state" % (args.steps + args.warmup),
-                   "collectives_per_sweep": 0 if not sharded else "1 all-gather of [3L+8] f64 statistics + 1 halo all-gather of 48 B per rank"},
+                   "collectives_per_sweep": 0 if not sharded else "1 all-gather of [3L+8] f64 statistics + 1 halo all-gather of 48 B per rank",
+                   "collectives_issued_by": None if not sharded else
+                   ("C library (ncclAllGather on the handle's stream)" if args.collectives == "library" and factory is None
+                    else "torch.distributed (all_gather_into_tensor)") + ((": " + collectives_note) if collectives_note else "")},
         "ranks_seen": ranks_seen,
         "setup_s": {"generate": round(job.t_gen, 2), "upload_and_prefilter": round(job.t_upload, 2)},
     }
@@ -461,7 +523,11 @@ def run_rank(args):
                           "unit": "pose-updates/s"}
         j3.close()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -482,6 +548,8 @@ def main():
                     help="N > 1: strong = the workload's sequence split N ways (BASELINE configs[4], the headline); "
                          "weak = the sequence has N x the workload's poses (fixed work per GPU); the other one is "
                          "reported as a secondary record")
+    ap.add_argument("--collectives", choices=("auto", "library", "torch"), default="auto",
+                    help="sharded runs: all-gathers issued by the C library (RCCL) or by torch.distributed; auto = library when it validates")
     ap.add_argument("--force-sharded", action="store_true",
                     help="drive even a 1-rank run through the sharded path (torch.distributed + RCCL all-gathers)")
     ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda", help="cpu: launcher tests only (with --engine-factory)")

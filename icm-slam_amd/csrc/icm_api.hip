@@ -7,7 +7,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen()ed (icm_comm_init), never linked
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
@@ -133,6 +136,10 @@ struct icm_handle {
     double* stats_all = nullptr;
     double *stats_send = nullptr, *halo_send = nullptr, *halo_all = nullptr;   // optional (icm_bind_exchange_send)
     int rank = 0, world = 1;
+    // collectives issued by the library itself (icm_comm_init): RCCL communicator + the exchange buffers it owns
+    ncclComm_t comm = nullptr;
+    DevBuf<double> own_stats_all, own_stats_send, own_halo_send, own_halo_all, own_poses;
+    int64_t comm_blk = 0;
     int64_t E = 0, n_new_loc = 0, lact_raw = 0;
     int lact0 = 0;
     bool brute = false, debug = false, per_beam = false, assoc_kept = false;
@@ -214,6 +221,47 @@ int icm_flop_per_eval(void) { return ICM_FLOP_PER_EVAL; }
 int icm_valu_per_eval(void) { return ICM_VALU_PER_EVAL; }
 
 const char* icm_last_error(const icm_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+// ---- RCCL from inside the library ------------------------------------------------------------
+// librccl is resolved at run time (the PyTorch-ROCm wheel bundles its own copy; a process must use
+// ONE of them, so whatever is already loaded wins).
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+} g_rccl;
+
+bool rccl_load(std::string& err) {
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    for (const char* n : names)   // already loaded by the host application?
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!lib)
+        for (const char* n : names)
+            if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) {
+        err = std::string("RCCL not found: ") + dlerror();
+        return false;
+    }
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(lib, "ncclAllGather"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
+        err = "RCCL: missing symbols";
+        return false;
+    }
+    g_rccl.lib = lib;
+    return true;
+}
+}  // namespace
+
 
 // The solve stream gets the highest priority: its few, register-hungry workgroups must win a slot
 // whenever one opens beside the phase A/B grids of the main stream.
@@ -308,6 +356,8 @@ int icm_destroy(icm_handle* h) {
     if (h->pin_i) (void)hipHostFree(h->pin_i);
     if (h->pin_d) (void)hipHostFree(h->pin_d);
     h->x_rows.release(); h->pack.release();
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+    h->own_stats_all.release(); h->own_stats_send.release(); h->own_halo_send.release(); h->own_halo_all.release(); h->own_poses.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_map) (void)hipEventDestroy(h->ev_map);
@@ -1350,6 +1400,108 @@ int icm_set_pipeline(icm_handle* h, int on) {
 }
 
 int icm_get_pipeline_used(const icm_handle* h) { return h ? h->pipe_used : ICM_ERR_ARG; }
+
+// ---- RCCL from inside the library: collectives (the loader is above icm_destroy) ----------------
+#define RCCLCHK(h, call)                                                                                     \
+    do {                                                                                                     \
+        ncclResult_t r__ = (call);                                                                           \
+        if (r__ != ncclSuccess) {                                                                            \
+            (h)->err = std::string(#call) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r__) : "RCCL error"); \
+            return ICM_ERR_HIP;                                                                              \
+        }                                                                                                    \
+    } while (0)
+
+int icm_comm_available(void) {
+    std::string err;
+    return rccl_load(err) ? 1 : 0;
+}
+
+int icm_comm_unique_id(void* id128) {
+    if (!id128) return ICM_ERR_ARG;
+    if (!rccl_load(g_create_err)) return ICM_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) {
+        g_create_err = "ncclGetUniqueId failed";
+        return ICM_ERR_HIP;
+    }
+    std::memcpy(id128, &id, sizeof(id));
+    return ICM_OK;
+}
+
+int icm_comm_init(icm_handle* h, const void* id128, int rank, int world) {
+    if (!h) return ICM_ERR_ARG;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) FAIL(h, ICM_ERR_ARG, "icm_comm_init: bad arguments");
+    if (!h->uploaded) FAIL(h, ICM_ERR_ARG, "icm_comm_init: upload this rank's shard first (icm_upload)");
+    if (h->comm) FAIL(h, ICM_ERR_ARG, "icm_comm_init: communicator already initialised");
+    if (!rccl_load(h->err)) return ICM_ERR_UNSUPPORTED;
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
+    const int64_t blk = (h->T + world - 1) / world;
+    if (h->t_begin != std::min<int64_t>((int64_t)rank * blk, h->T) || h->t_begin + h->nloc != std::min<int64_t>((int64_t)(rank + 1) * blk, h->T))
+        FAIL(h, ICM_ERR_ARG, "icm_comm_init: the uploaded shard is not block `rank` of ceil(T / world)-pose blocks");
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    RCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
+    const size_t stride = (size_t)icm_stats_stride(h);
+    HIPCHK(h, h->own_stats_all.reserve((size_t)world * stride));
+    HIPCHK(h, h->own_stats_send.reserve(stride));
+    HIPCHK(h, h->own_halo_send.reserve(8));
+    HIPCHK(h, h->own_halo_all.reserve(6 * (size_t)world + 2));
+    HIPCHK(h, h->own_poses.reserve((size_t)world * (size_t)blk * 3));
+    HIPCHK(h, hipMemsetAsync(h->own_stats_all.p, 0, (size_t)world * stride * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->own_stats_send.p, 0, stride * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->own_poses.p, 0, (size_t)world * (size_t)blk * 3 * sizeof(double), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->comm_blk = blk;
+    int rc;
+    if ((rc = icm_bind_exchange(h, h->own_stats_all.p, rank, world))) return rc;
+    if ((rc = icm_bind_pose_buffer(h, h->own_poses.p))) return rc;
+    return icm_bind_exchange_send(h, h->own_stats_send.p, h->own_halo_send.p, h->own_halo_all.p);
+}
+
+int icm_comm_destroy(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    if (h->comm) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        (void)g_rccl.CommDestroy(h->comm);
+        h->comm = nullptr;
+    }
+    return ICM_OK;
+}
+
+// One red-black sweep of a sharded sequence, the collectives issued here, on the handle's stream:
+// local phase A + statistics -> all-gather of the [3L+8] statistics -> targets -> odd poses ->
+// all-gather of the 48-byte halos -> even poses -> Mapa.filtrar (replicated).  
+int icm_sweep_sharded(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->comm) FAIL(h, ICM_ERR_ARG, "icm_sweep_sharded: no communicator (icm_comm_init)");
+    int rc;
+    if ((rc = icm_sweep_local(h))) return rc;
+    const size_t stride = (size_t)icm_stats_stride(h);
+    RCCLCHK(h, g_rccl.AllGather(h->own_stats_send.p, h->own_stats_all.p, stride, ncclDouble, h->comm, h->stream));
+    if ((rc = icm_sweep_targets(h))) return rc;
+    if (h->world == 1) {   // no neighbour, no halo: both colours in the one-launch solve
+        if ((rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, -1))) return rc;
+        return icm_sweep_finish(h);
+    }
+    if ((rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, 1))) return rc;
+    RCCLCHK(h, g_rccl.AllGather(h->own_halo_send.p, h->own_halo_all.p, 6, ncclDouble, h->comm, h->stream));
+    if ((rc = icm_halo_unpack(h))) return rc;
+    if ((rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, 0))) return rc;   // (its boundary values ride in the next statistics message)
+    return icm_sweep_finish(h);
+}
+
+// Every rank's pose block -> every rank (before icm_get_state on a sharded handle).
+int icm_gather_poses(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->comm) FAIL(h, ICM_ERR_ARG, "icm_gather_poses: no communicator (icm_comm_init)");
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcj = join_solves(h); if (rcj) return rcj; }
+    const size_t cnt = (size_t)h->comm_blk * 3;
+    RCCLCHK(h, g_rccl.AllGather(h->own_poses.p + (size_t)h->rank * cnt, h->own_poses.p, cnt, ncclDouble, h->comm, h->stream));
+    return ICM_OK;
+}
 
 int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out, int64_t* K_out) {
     if (!h) return ICM_ERR_ARG;

@@ -49,6 +49,12 @@ SIGNATURES = {
     "icm_halo_unpack": (C.c_int, [_H]),
     "icm_bind_pose_buffer": (C.c_int, [_H, C.c_void_p]),
     "icm_pose_buffer": (C.c_void_p, [_H]),
+    "icm_comm_available": (C.c_int, []),
+    "icm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "icm_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    "icm_comm_destroy": (C.c_int, [_H]),
+    "icm_sweep_sharded": (C.c_int, [_H]),
+    "icm_gather_poses": (C.c_int, [_H]),
     "icm_sweep_local": (C.c_int, [_H]),
     "icm_sweep_targets": (C.c_int, [_H]),
     "icm_sweep_solve": (C.c_int, [_H, C.c_int, C.c_int]),

@@ -311,6 +311,29 @@ class SweepEngine:
     def pose_buffer(self):
         return self.lib.icm_pose_buffer(self.h)
 
+    # ---- collectives issued by the library (RCCL on the handle's stream) ---------------------
+    def comm_available(self):
+        return bool(self.lib.icm_comm_available())
+
+    def comm_unique_id(self):
+        """128-byte RCCL id (rank 0 makes it, every rank passes it to comm_init)."""
+        buf = (C.c_ubyte * 128)()
+        self._chk(self.lib.icm_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def comm_init(self, id128, rank, world):
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
+        self._chk(self.lib.icm_comm_init(self.h, C.cast(buf, C.c_void_p), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._chk(self.lib.icm_comm_destroy(self.h))
+
+    def sweep_sharded(self):
+        self._chk(self.lib.icm_sweep_sharded(self.h))
+
+    def gather_poses(self):
+        self._chk(self.lib.icm_gather_poses(self.h))
+
     # ---- inspection ----------------------------------------------------------------------
     def association(self):
         n = max(self.nnz, 1)

@@ -114,6 +114,49 @@ class ShardedSweep:
         return self.eng.get_state()
 
 
+class LibrarySweep:
+    """One rank of a pose-sharded sweep whose collectives the C library issues itself (RCCL
+    `ncclAllGather` on the handle's stream: `icm_comm_init` / `icm_sweep_sharded`, include/icmslam.h) --
+    a sweep is ONE C call, nothing of it runs through Python or torch.distributed.  The 128-byte
+    communicator id travels once, by `bcast(bytes_or_None) -> bytes` (rank 0 passes the id, the others
+    None); default: a broadcast on the default torch.distributed group, whatever its backend."""
+
+    def __init__(self, engine, rank, world, T, bcast=None):
+        self.eng, self.rank, self.world, self.T = engine, rank, world, T
+        self.blk, self.parts = partition(T, world)
+        self.own = self.parts[rank]
+        if bcast is None:
+            bcast = _torch_bcast
+        uid = bcast(engine.comm_unique_id() if rank == 0 else None)
+        engine.comm_init(uid, rank, world)
+
+    def set_state(self, mapa_viejo, x, x0, lact=None):
+        self.eng.set_state(mapa_viejo, x, x0, lact)
+
+    def sweep(self, schedule="redblack"):
+        if schedule != "redblack":
+            raise NotImplementedError("only the red-black schedule shards (the reference order is one chain)")
+        self.eng.sweep_sharded()
+
+    def get_state(self):
+        self.eng.gather_poses()
+        return self.eng.get_state()
+
+    def close(self):
+        self.eng.comm_destroy()
+
+
+def _torch_bcast(payload):
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if payload is not None:
+        t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    dist.broadcast(t, src=0)
+    return bytes(t.cpu().numpy().tobytes())
+
+
 class TorchComm:
     """all_gather_into_tensor on the default process group (NCCL/RCCL on GPUs, gloo on CPU)."""
 

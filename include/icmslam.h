@@ -141,6 +141,20 @@ int icm_halo_unpack(icm_handle *h);
  * before icm_set_state. */
 int icm_bind_pose_buffer(icm_handle *h, void *x_dev);
 void *icm_pose_buffer(icm_handle *h);                 /* device pointer of x (T,3)          */
+/* Collectives issued by the library itself (RCCL over xGMI, resolved with dlopen at run time)
+ * instead of by the caller: rank 0 makes an id (icm_comm_unique_id, 128 bytes) and hands it to every
+ * rank by whatever means the application has; each rank, after uploading block `rank` of
+ * ceil(T / world)-pose blocks, calls icm_comm_init, which creates the communicator and allocates and
+ * binds the exchange buffers (statistics, halos, replicated pose array).  icm_sweep_sharded then is
+ * one whole red-black sweep -- phase A, all-gather of the statistics, targets, odd poses, all-gather
+ * of the halos, even poses, Mapa.filtrar -- with both collectives on the handle's stream;
+ * icm_gather_poses all-gathers the pose blocks before icm_get_state. */
+int icm_comm_available(void);                         /* 1 when an RCCL library can be resolved */
+int icm_comm_unique_id(void *id128);
+int icm_comm_init(icm_handle *h, const void *id128, int rank, int world);
+int icm_comm_destroy(icm_handle *h);
+int icm_sweep_sharded(icm_handle *h);
+int icm_gather_poses(icm_handle *h);
 int icm_sweep_local(icm_handle *h);                   /* phase A + local statistics          */
 int icm_sweep_targets(icm_handle *h);                 /* prefix over ranks -> targets, map   */
 int icm_sweep_solve(icm_handle *h, int schedule, int colour); /* colour 1 = odd, 0 = even,  */

@@ -85,6 +85,41 @@ def test_rccl_all_gather_path_one_rank():
     assert K == K1 and np.array_equal(x, x1) and np.array_equal(m, m1)
 
 
+def test_library_collectives_one_rank():
+    """The collectives issued by the C library itself (icm_comm_init / icm_sweep_sharded /
+    icm_gather_poses: RCCL resolved with dlopen, all-gathers on the handle's stream), world size 1 --
+    no torch.distributed anywhere: same state as the plain device-resident sweep, bit for bit."""
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import LibrarySweep
+    wl, cfg = _workload()
+    x1, m1, c1, K1 = _single(wl, cfg, 3)
+    e = SweepEngine(cfg)
+    assert e.comm_available()
+    e.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    run = LibrarySweep(e, 0, 1, wl.T, bcast=lambda payload: payload)
+    run.set_state(wl.map_init, wl.x_init, wl.x0)
+    for _ in range(3):
+        run.sweep("redblack")
+    x, m, c, K = run.get_state()
+    run.close()
+    e.close()
+    assert K == K1 and np.array_equal(x, x1) and np.array_equal(m, m1) and np.array_equal(c, c1)
+
+
+def test_library_collectives_refuse_a_wrong_partition():
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.engine import IcmError
+    wl, cfg = _workload()
+    e = SweepEngine(cfg)
+    e.upload(wl.scans[:100], wl.odometry, wl.u, t_begin=0, t_end=100, pose_major=True)
+    uid = e.comm_unique_id()
+    with pytest.raises((IcmError, ValueError)):
+        e.comm_init(uid, 0, 1)          # 100 poses are not block 0 of a 1-rank partition of T poses
+    with pytest.raises((IcmError, ValueError)):
+        e.sweep_sharded()               # no communicator
+    e.close()
+
+
 def _native_worker(rank, world, port, out_path):
     """One rank of a multi-process sharded sweep; every rank uses cuda:0 (one-GPU box), the
     collectives go through gloo -- the path under test is the library's send-side buffers
