@@ -9,7 +9,7 @@
 using namespace icm;
 
 extern "C" __global__ void k_eval_probe(const SolveCtx* __restrict__ c, const PoseMoments* __restrict__ m,
-                                        const double* __restrict__ p, double* __restrict__ out) {
+                                        const PoseFold* __restrict__ f, const double* __restrict__ p, double* __restrict__ out) {
     const int i = threadIdx.x;
-    out[i] = pose_energy_moments(*c, *m, p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+    out[i] = pose_energy_moments(*c, *m, *f, p[3 * i], p[3 * i + 1], p[3 * i + 2]);
 }

@@ -1888,6 +1888,14 @@ int icm_set_debug(icm_handle* h, int on) {
     return ICM_OK;
 }
 
+#ifdef ICM_WAVE_TS
+int icm_debug_wave_ts(icm_handle* h, unsigned long long* out, int n4) {
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(icm::g_wave_ts), sizeof(unsigned long long) * (size_t)n4));
+    return ICM_OK;
+}
+#endif
+
 int icm_get_solve_diag(icm_handle* h, double* out) {
     if (!h || !out) return ICM_ERR_ARG;
     if (!h->diag.p) FAIL(h, ICM_ERR_ARG, "icm_get_solve_diag: enable icm_set_debug before the sweep");

@@ -317,17 +317,94 @@ __device__ __noinline__ double pose_energy_moments_generic(const SolveCtx& c, co
     return pose_energy_moments_t<true>(c, m, px, py, th, dl, a0, a1, a2, a3);
 }
 
-__device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const PoseMoments& m, double px, double py,
-                                                      double th) {
-    const double dl = th - m.tho;
-    const double a0 = th - c.gat;              // prev: model residual angle
-    const double a1 = (c.o1t - th) + c.xat;    // prev: odometry residual angle
-    const double a2 = (th + c.dtw) - c.xpt;    // next: model residual angle
-    const double a3 = c.o2tp + th;             // next: odometry residual angle, (o2t - xpt) + th
-    const bool fast = (int)(fabs(dl) <= 0.25) & (int)(fabs(a0) < kTwoPi) & (int)(fabs(a1) < kTwoPi) & (int)(fabs(a2) < kTwoPi) & (int)(fabs(a3) < kTwoPi);
-    if (!ICM_PROBE_FAST_TRIG_ONLY && __builtin_expect(__ballot(!fast) != 0ull, 0))
-        return pose_energy_moments_generic(c, m, px, py, th, dl, a0, a1, a2, a3);
-    return pose_energy_moments_t<false>(c, m, px, py, th, dl, a0, a1, a2, a3);
+// ---------------------------------------------------------------------------------------
+// Folded form: what a Nelder-Mead evaluation actually executes.
+// With isotropic weights (Q0 == Q1, R0 == R1) and no angle wrap in play, EVERY term of
+// fun_xn / fun_x is a polynomial of degree <= 2 in the planar step d = p - p_o about the pose's
+// previous-sweep value, whose coefficients are linear in al = cos dl - 1, be = sin dl (dl = th - th_o),
+// plus a quadratic in dl from the four angle residuals:
+//   moment-form h          Q [S |d|^2 + 2 d.(g0 + al Sw + be J Sw) + 2 (al AW + be Bq) + Rr] + sc
+//   previous pose, model   Rp |d + u|^2 + R2 (dl + k0)^2                      u = p_o - g(a)
+//   previous pose, odom.   cte (|d + v|^2 + (k1 - dl)^2)                      v = p_o - (a + Rot(a)^T o1)
+//   next pose, model       Rp |d + e0 + dtv (al c_o + be J c_o)|^2 + R2 (dl + k2)^2,   e0 = (p_o - b) + dtv c_o,
+//                          c_o = (cos th_o, sin th_o); |al c_o + be J c_o|^2 = al^2 + be^2 = -2 al exactly
+//   next pose, odometry    cte (|o2 + Rot(th)(d + w)|^2 + (dl + k3)^2) = cte (|d + w|^2 + |o2|^2 + 2 (d + w).q(th) + ...),
+//                          w = p_o - b, q(th) = Rot(th)^T o2 = q0 (1 + al) + be J q0, q0 = Rot(th_o)^T o2
+// so that
+//   E = A |d|^2 + dx (B0 + B1 al + B2 be) + dy (C0 - B2 al + B1 be) + D1 al + D2 be + dl (V2 + W dl) + D0
+// with thirteen per-pose numbers (make_fold, once per solve): ~35 vector instructions per evaluation
+// instead of ~145 for the term-by-term form, and a third of its registers.  Every folded coefficient is a
+// sum of O(residual) or O(residual^2) quantities (the expansion point is the pose phase A projected with),
+// so nothing cancels; the folded value differs from the term-by-term one by a few ulps of E.
+// Validity is decided PER LANE from the lane's own data (never from its wave mates): |dl| <= dlim, where
+// dlim = min(0.25 (polynomial sin / cos), 3 - max |k_i| (no residual angle reaches +-pi)), dlim < 0 for
+// anisotropic weights.  A lane outside it takes the term-by-term form (pose_energy_moments_generic: generic
+// sincos, entrepi with its fmod); the wave executes that call only when one of its lanes needs it.
+// For |a| < pi entrepi(a) is a up to the rounding of its +2 pi / -2 pi round trip (<= 4.5e-16 absolute), far
+// below one ulp of E once squared and weighted.
+// ---------------------------------------------------------------------------------------
+struct PoseFold {
+    double pox, poy, tho;
+    double A, B0, B1, B2, C0, D0, D1, D2, W, V2;
+    double dlim;
+};
+
+__device__ __forceinline__ void make_fold(const SolveCtx& c, const PoseMoments& m, PoseFold& f) {
+    f.pox = m.pox; f.poy = m.poy; f.tho = m.tho;
+    const double Q = c.Q0, Rp = c.R0, wn = c.wn, co = m.co, so = m.so;
+    const double ux = m.pox - c.gax, uy = m.poy - c.gay;
+    const double vx = m.pox - c.hx, vy = m.poy - c.hy;
+    const double wx = m.pox - c.xpx, wy = m.poy - c.xpy;        // (times wn = 0 for a one-sided energy)
+    const double ex0 = wx + c.dtv * co, ey0 = wy + c.dtv * so;
+    const double qx0 = c.o2x * co - c.o2y * so, qy0 = c.o2x * so + c.o2y * co;
+    const double zx = wx + qx0, zy = wy + qy0;
+    const double nR = wn * Rp, nO = wn * c.cte;
+    f.A = (Q * m.S + Rp) + (c.cte + (nR + nO));
+    f.B0 = 2.0 * (((Q * m.Srx + Rp * ux) + c.cte * vx) + (nR * ex0 + nO * zx));
+    f.C0 = 2.0 * (((Q * m.Sry + Rp * uy) + c.cte * vy) + (nR * ey0 + nO * zy));
+    f.B1 = 2.0 * (Q * m.Swx + (nR * (c.dtv * co) + nO * qx0));
+    f.B2 = -2.0 * (Q * m.Swy + (nR * (c.dtv * so) + nO * qy0));
+    f.D1 = 2.0 * ((Q * m.AW + nR * (c.dtv * ((ex0 * co + ey0 * so) - c.dtv))) + nO * (wx * qx0 + wy * qy0));
+    f.D2 = 2.0 * ((Q * m.Bq + nR * (c.dtv * (ey0 * co - ex0 * so))) + nO * (wy * qx0 - wx * qy0));
+    const double k0 = m.tho - c.gat, k1 = (c.o1t - m.tho) + c.xat, k2 = (m.tho + c.dtw) - c.xpt, k3 = c.o2tp + m.tho;
+    const double nA = wn * c.R2;
+    f.W = (c.R2 + c.cte) + (nA + nO);
+    f.V2 = 2.0 * ((c.R2 * k0 - c.cte * k1) + (nA * k2 + nO * k3));
+    f.D0 = (((Q * m.Rr + m.sc_iso) + Rp * (ux * ux + uy * uy)) + c.cte * (vx * vx + vy * vy)) +
+           ((nR * (ex0 * ex0 + ey0 * ey0) + nO * (zx * zx + zy * zy)) +
+            ((c.R2 * (k0 * k0) + c.cte * (k1 * k1)) + (nA * (k2 * k2) + nO * (k3 * k3))));
+    double kmax = fmax(fabs(k0), fabs(k1));
+    if (wn != 0.0) kmax = fmax(kmax, fmax(fabs(k2), fabs(k3)));
+    const bool iso = c.Q0 == c.Q1 && c.R0 == c.R1;
+    f.dlim = (iso && kmax < 3.0) ? fmin(0.25, 3.0 - kmax) : -1.0;   // (NaN anywhere -> -1: the term-by-term form)
+}
+
+__device__ __forceinline__ double pose_energy_folded(const PoseFold& f, double px, double py, double dl) {
+    double al, be;
+    small_sincosm1(dl, be, al);
+    const double dx = px - f.pox, dy = py - f.poy;
+    const double l1 = fma_(f.B1, al, fma_(f.B2, be, f.B0));
+    const double l2 = fma_(f.B1, be, fnma_(f.B2, al, f.C0));
+    const double l3 = fma_(f.D1, al, fma_(f.D2, be, fma_(dl, fma_(f.W, dl, f.V2), f.D0)));
+    const double rr = fma_(dx, dx, dy * dy);
+    return fma_(f.A, rr, fma_(dx, l1, fma_(dy, l2, l3)));
+}
+
+__device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const PoseMoments& m, const PoseFold& f, double px,
+                                                      double py, double th) {
+    const double dl = th - f.tho;
+    double e = pose_energy_folded(f, px, py, dl);
+    if (ICM_PROBE_FAST_TRIG_ONLY) return e;
+    const bool folded = fabs(dl) <= f.dlim;
+    if (__builtin_expect(__ballot(!folded) != 0ull, 0)) {
+        const double a0 = th - c.gat;              // prev: model residual angle
+        const double a1 = (c.o1t - th) + c.xat;    // prev: odometry residual angle
+        const double a2 = (th + c.dtw) - c.xpt;    // next: model residual angle
+        const double a3 = c.o2tp + th;             // next: odometry residual angle, (o2t - xpt) + th
+        const double g = pose_energy_moments_generic(c, m, px, py, th, dl, a0, a1, a2, a3);
+        e = folded ? e : g;
+    }
+    return e;
 }
 
 // fun_xn (two_sided) / fun_x (reference scripts/ICM_ROS.py:220-278), Appendix A.4, given

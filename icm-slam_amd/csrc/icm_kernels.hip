@@ -2107,6 +2107,8 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
     m.tho = a.x[3 * (size_t)tg + 2];
     m.so = sin(m.tho);  // (no sincos(&member): an address-taken struct member forces scratch)
     m.co = cos(m.tho);
+    PoseFold f;
+    make_fold(c, m, f);
     double sx, sy, st;
     if (!last) {
         sx = (prev[0] + xp[0]) / 2.0; sy = (prev[1] + xp[1]) / 2.0; st = (prev[2] + xp[2]) / 2.0;
@@ -2115,9 +2117,9 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
     }
     double out[6];
     if (QUAD)
-        nelder_mead3_quad([&](double px, double py, double th) { return pose_energy_moments(c, m, px, py, th); }, sx, sy, st, role, out);
+        nelder_mead3_quad([&](double px, double py, double th) { return pose_energy_moments(c, m, f, px, py, th); }, sx, sy, st, role, out);
     else
-        nelder_mead3([&](double px, double py, double th) { return pose_energy_moments(c, m, px, py, th); }, sx, sy, st, out);
+        nelder_mead3([&](double px, double py, double th) { return pose_energy_moments(c, m, f, px, py, th); }, sx, sy, st, out);
     res[0] = out[0]; res[1] = out[1]; res[2] = out[2];
     if (a.diag && role == 0) {
         a.diag[3 * (size_t)tg] = out[3];
@@ -2191,8 +2193,21 @@ __device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, const Solve
     }
 }
 
+#ifndef ICM_SOLVE_WPE
+#define ICM_SOLVE_WPE 1
+#endif
+#ifndef ICM_SOLVEQ_WPE
+#define ICM_SOLVEQ_WPE 1
+#endif
+#ifdef ICM_WAVE_TS   // measurement builds only (scratch/wave_timeline.py): per-wave start / go / end times
+__device__ unsigned long long g_wave_ts[4 * 16384];
+#define WAVE_TS(slot) do { if (lane == 0 && gw < 16384) g_wave_ts[4 * gw + (slot)] = wall_clock64(); } while (0)
+#else
+#define WAVE_TS(slot) do { } while (0)
+#endif
 template <bool QUAD>
-__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags, int epoch,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(QUAD ? ICM_SOLVEQ_WPE : ICM_SOLVE_WPE, QUAD ? ICM_SOLVEQ_WPE : ICM_SOLVE_WPE)))
+void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags, int epoch,
                                                           int spin_limit, int* __restrict__ deferred) {
     const int lane = lane_id();
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -2200,6 +2215,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
     if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;   // (uniform over the whole grid)
     const bool even = gw >= nw;
     const int wv = even ? gw - nw : gw;
+    WAVE_TS(0);
     if (even) {
         int ready = 1;
         if (lane == 0) {
@@ -2222,7 +2238,9 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    WAVE_TS(1);
     solve_wave_poses<QUAD>(a, g, even, wv, lane);
+    WAVE_TS(2);
     if (!even) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
