@@ -1894,6 +1894,15 @@ int icm_debug_wave_ts(icm_handle* h, unsigned long long* out, int n4) {
     HIPCHK(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(icm::g_wave_ts), sizeof(unsigned long long) * (size_t)n4));
     return ICM_OK;
 }
+int icm_debug_eval_stats(icm_handle* h, unsigned long long* out4, int reset) {
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpyFromSymbol(out4, HIP_SYMBOL(icm::g_eval_stats), sizeof(unsigned long long) * 4));
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(icm::g_eval_stats), z, sizeof(z)));
+    }
+    return ICM_OK;
+}
 #endif
 
 int icm_get_solve_diag(icm_handle* h, double* out) {

@@ -17,6 +17,9 @@ constexpr int kWave = 64;
 // 1 only in eval_probe.hip (tools/count_eval_flops.py): the rarely taken slow paths (fmod in
 // wrap_pi, generic sincos beyond |d| = 0.25) are compiled out so that the probe's ISA is the
 // straight-line path an energy evaluation executes with the default isotropic Q.
+#ifndef ICM_EXPERIMENT_FOLD_ONLY
+#define ICM_EXPERIMENT_FOLD_ONLY 0
+#endif
 #ifndef ICM_PROBE_FAST_TRIG_ONLY
 #define ICM_PROBE_FAST_TRIG_ONLY 0
 #endif
@@ -343,6 +346,9 @@ __device__ __noinline__ double pose_energy_moments_generic(const SolveCtx& c, co
 // For |a| < pi entrepi(a) is a up to the rounding of its +2 pi / -2 pi round trip (<= 4.5e-16 absolute), far
 // below one ulp of E once squared and weighted.
 // ---------------------------------------------------------------------------------------
+#ifdef ICM_WAVE_TS
+__device__ unsigned long long g_eval_stats[4];   // wave evaluations, of which generic; lane evaluations, of which generic
+#endif
 struct PoseFold {
     double pox, poy, tho;
     double A, B0, B1, B2, C0, D0, D1, D2, W, V2;
@@ -394,8 +400,19 @@ __device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const P
                                                       double py, double th) {
     const double dl = th - f.tho;
     double e = pose_energy_folded(f, px, py, dl);
-    if (ICM_PROBE_FAST_TRIG_ONLY) return e;
+    if (ICM_PROBE_FAST_TRIG_ONLY || ICM_EXPERIMENT_FOLD_ONLY) return e;
     const bool folded = fabs(dl) <= f.dlim;
+#ifdef ICM_WAVE_TS
+    {
+        const unsigned long long act = __ballot(true), gen = __ballot(!folded);
+        if ((unsigned)__builtin_ctzll(act) == (threadIdx.x & 63)) {
+            atomicAdd(&g_eval_stats[0], 1ull);
+            atomicAdd(&g_eval_stats[1], (unsigned long long)(gen != 0));
+            atomicAdd(&g_eval_stats[2], (unsigned long long)__builtin_popcountll(act));
+            atomicAdd(&g_eval_stats[3], (unsigned long long)__builtin_popcountll(gen));
+        }
+    }
+#endif
     if (__builtin_expect(__ballot(!folded) != 0ull, 0)) {
         const double a0 = th - c.gat;              // prev: model residual angle
         const double a1 = (c.o1t - th) + c.xat;    // prev: odometry residual angle

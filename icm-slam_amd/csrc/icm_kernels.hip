@@ -2158,9 +2158,10 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
 // -- behind the kernel boundary every odd pose is final -- and clears the marks.  With the
 // observed dispatch (lower workgroup ids first) no wave ever defers and that launch is empty;
 // under any other dispatch order the sweep is slower, never wrong and never stuck.
-// Hand-off per MI355X_MICROARCH.md: producer = plain stores, vmcnt(0), agent release fence,
-// vmcnt(0), relaxed agent flag store; consumer = relaxed polls, ONE agent acquire fence,
-// vmcnt(0), then plain loads.  The odd waves that READ an even wave's poses (as the old values of
+// Hand-off per MI355X_MICROARCH.md (valid forms): producer = write-through (sc1, agent-scope) stores of the
+// poses, vmcnt(0), relaxed agent flag store -- no cache-wide release (782 odd waves each writing back their
+// XCD's whole L2 queued behind one another: the even waves started 19 us after their flags' poses were
+// final); consumer = relaxed polls, ONE agent acquire fence, vmcnt(0), then plain loads.  The odd waves that READ an even wave's poses (as the old values of
 // their neighbours) are exactly the two it waits for, so nothing is overwritten while in use.
 // QUAD: the latency form (one DPP quad per pose, 16 poses per wave) with the same dependency rule.
 // A time segment of the sequence solved by one launch: poses [t0, t1).  shift = 0 for the segment
@@ -2186,19 +2187,19 @@ __device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, const Solve
         double res[3];
         solve_pose_moments<QUAD>(a, tg, prev, res, role);
         if (role == 0) {
-            a.x[3 * (size_t)tg] = res[0];
-            a.x[3 * (size_t)tg + 1] = res[1];
-            a.x[3 * (size_t)tg + 2] = res[2];
+            if (!even) {   // handed to the even waves of this launch: write-through (sc1) stores, no cache-wide release needed
+                __hip_atomic_store(&a.x[3 * (size_t)tg], res[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.x[3 * (size_t)tg + 1], res[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.x[3 * (size_t)tg + 2], res[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                a.x[3 * (size_t)tg] = res[0];
+                a.x[3 * (size_t)tg + 1] = res[1];
+                a.x[3 * (size_t)tg + 2] = res[2];
+            }
         }
     }
 }
 
-#ifndef ICM_SOLVE_WPE
-#define ICM_SOLVE_WPE 1
-#endif
-#ifndef ICM_SOLVEQ_WPE
-#define ICM_SOLVEQ_WPE 1
-#endif
 #ifdef ICM_WAVE_TS   // measurement builds only (scratch/wave_timeline.py): per-wave start / go / end times
 __device__ unsigned long long g_wave_ts[4 * 16384];
 #define WAVE_TS(slot) do { if (lane == 0 && gw < 16384) g_wave_ts[4 * gw + (slot)] = wall_clock64(); } while (0)
@@ -2206,8 +2207,7 @@ __device__ unsigned long long g_wave_ts[4 * 16384];
 #define WAVE_TS(slot) do { } while (0)
 #endif
 template <bool QUAD>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(QUAD ? ICM_SOLVEQ_WPE : ICM_SOLVE_WPE, QUAD ? ICM_SOLVEQ_WPE : ICM_SOLVE_WPE)))
-void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags, int epoch,
+__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags, int epoch,
                                                           int spin_limit, int* __restrict__ deferred) {
     const int lane = lane_id();
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -2242,10 +2242,9 @@ void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags, i
     solve_wave_poses<QUAD>(a, g, even, wv, lane);
     WAVE_TS(2);
     if (!even) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every write-through store of this wave has been acknowledged
         if (lane == 0) __hip_atomic_store(&flags[wv], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        WAVE_TS(3);
     }
 }
 
