@@ -564,6 +564,14 @@ __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double s
     }
     int nfev = 4, it = 1;
     sort4(v0, v1, v2, v3);
+    // The iteration is written as straight-line code with selects: every lane computes the reflection AND a
+    // second point (lanes that accept the reflection as it is compute a point they discard), decisions are
+    // predicates, and only the rare events -- a shrink, the evaluation budget running out -- are branches.
+    // A wavefront executes both evaluations of an iteration anyway as soon as one of its 64 poses needs the
+    // second one, so the predicated form costs nothing extra and drops the exec-mask bookkeeping of nested
+    // branches (a third of the instructions of an iteration).  Same arithmetic, same decisions:
+    //   2 xbar - x_w           = fma(2, xbar, -x_w)        (2 xbar is exact)
+    //   ca xbar + cb x_w       = fma(cb, x_w, ca xbar)     (cb = -2, -0.5, 0.5: cb x_w is exact)
     while (nfev < maxfun && it < maxiter) {
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
@@ -571,32 +579,34 @@ __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double s
         const double bx = div3((v0.x + v1.x) + v2.x);
         const double by = div3((v0.y + v1.y) + v2.y);
         const double bt = div3((v0.t + v1.t) + v2.t);
-        Vtx r{2 * bx - v3.x, 2 * by - v3.y, 2 * bt - v3.t, 0.0};
+        Vtx r{fmas_(2.0, bx, v3.x), fmas_(2.0, by, v3.y), fmas_(2.0, bt, v3.t), 0.0};
         r.f = f(r.x, r.y, r.t);
         ++nfev;
-        // second point of the iteration: 1 expansion, 2 outside, 3 inside contraction, 0 none
-        int kind = 0;
-        double ca = 0.0, cb = 0.0;  // t = ca * xbar + cb * sim[-1]
-        if (r.f < v0.f) { kind = 1; ca = 3.0; cb = -2.0; }
-        else if (r.f < v2.f) { kind = 0; }
-        else if (r.f < v3.f) { kind = 2; ca = 1.5; cb = -0.5; }
-        else { kind = 3; ca = 0.5; cb = 0.5; }
-        bool shrink = false, aborted = false;
-        if (kind != 0) {
-            if (nfev >= maxfun) {
-                aborted = true;
-            } else {
-                Vtx t{ca * bx + cb * v3.x, ca * by + cb * v3.y, ca * bt + cb * v3.t, 0.0};
-                t.f = f(t.x, t.y, t.t);
-                ++nfev;
-                if (kind == 1) v3 = (t.f < r.f) ? t : r;
-                else if (kind == 2) { if (t.f <= r.f) v3 = t; else shrink = true; }
-                else { if (t.f < v3.f) v3 = t; else shrink = true; }
-            }
-        } else {
-            v3 = r;
+        // second point of the iteration: expansion (fr < f0), outside (f2 <= fr < f3) or inside (fr >= f3)
+        // contraction; none when f0 <= fr < f2
+        // (bitwise operators on the predicates: lane-mask algebra, no short-circuit branches)
+        const bool lt0 = r.f < v0.f, lt2 = r.f < v2.f, lt3 = r.f < v3.f;
+        const bool need2 = lt0 | !lt2;
+        const bool can2 = need2 & (nfev < maxfun);      // (a call beyond maxfun aborts the iteration, SciPy's _MaxFuncCallError)
+        // ca = 3, 1.5, 0.5 and cb = -2, -0.5, 0.5: only the high words differ
+        const int ca_hi = lt0 ? 0x40080000 : (lt3 ? 0x3FF80000 : 0x3FE00000);
+        const int cb_hi = lt0 ? (int)0xC0000000 : (lt3 ? (int)0xBFE00000 : 0x3FE00000);
+        const double ca = __hiloint2double(ca_hi, 0), cb = __hiloint2double(cb_hi, 0);
+        Vtx t{fma_(cb, v3.x, ca * bx), fma_(cb, v3.y, ca * by), fma_(cb, v3.t, ca * bt), 0.0};
+        t.f = f(t.x, t.y, t.t);
+        nfev += can2 ? 1 : 0;
+        const bool t_lt_r = t.f < r.f, t_le_r = t.f <= r.f, t_lt_w = t.f < v3.f;
+        const bool take_t = (lt0 & t_lt_r) | (!lt0 & lt3 & t_le_r) | (!lt3 & t_lt_w);   // (!lt3 implies !lt0: f0 <= f3)
+        const bool shrink = can2 & !lt0 & !take_t;
+        const bool aborted0 = need2 & !can2;
+        const bool use_t = can2 & take_t;
+        const bool keep = shrink | aborted0;
+        {
+            const double nx = use_t ? t.x : r.x, ny = use_t ? t.y : r.y, nt = use_t ? t.t : r.t, nf = use_t ? t.f : r.f;
+            v3.x = keep ? v3.x : nx; v3.y = keep ? v3.y : ny; v3.t = keep ? v3.t : nt; v3.f = keep ? v3.f : nf;
         }
-        if (shrink) {
+        bool aborted = aborted0;
+        if (__builtin_expect(shrink, 0)) {
 #pragma unroll 1
             for (int j = 1; j < 4; ++j) {
                 // sim[j] = sim[0] + sigma (sim[j] - sim[0]) is stored before the call that may abort
