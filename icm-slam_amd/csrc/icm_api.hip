@@ -442,6 +442,7 @@ int icm_upload(icm_handle* h, const double* ranges, const double* odo, const dou
 // Buffers of the landmark table, its search grid and Mapa.filtrar (sized by L alone).
 static int reserve_map_buffers(icm_handle* h) {
     const size_t L = (size_t)h->cfg.L;
+    if (8 * (int64_t)L + 4096 > (int64_t)1 << 25) FAIL(h, ICM_ERR_CAPACITY, "landmark capacity L too large for the search grid's 32-bit record offsets (L <= 4 193 792)");
     h->max_cells = (int)(8 * L + 4096);   // bound of both grid builders (build_grid on the host, k_fl_* on the device)
     const size_t nc = (size_t)h->max_cells + 2;
     HIPCHK(h, h->y_raw.reserve(2 * L)); HIPCHK(h, h->cnt_raw.reserve(L));

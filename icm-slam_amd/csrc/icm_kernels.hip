@@ -427,32 +427,33 @@ __device__ __noinline__ int assoc_grid_walk(const GridView& g, const GridParams&
 __device__ __forceinline__ int assoc_grid(const GridView& g, const GridParams& gp, double wx, double wy, double thr,
                                           double thr2) {
     const int cx = grid_cell(wx, gp.gx0, gp.inv, gp.nx), cy = grid_cell(wy, gp.gy0, gp.inv, gp.ny);
-    const NeighRec* __restrict__ r = g.nb + ((size_t)cy * gp.nx + cx);
-    const double4 xa = *reinterpret_cast<const double4*>(r->x), ya = *reinterpret_cast<const double4*>(r->y);
-    const int4 ia = *reinterpret_cast<const int4*>(r->id);
-    const int n = r->n;
-    double best = __builtin_huge_val(), second = __builtin_huge_val();
-    int bid = -1;
-#define ICM_CAND(XX, YY, ID)                       \
-    {                                              \
-        const double dx = XX - wx, dy = YY - wy;   \
-        const double sq = dx * dx + dy * dy;       \
-        if (sq < best) {                           \
-            second = best;                         \
-            best = sq;                             \
-            bid = ID;                              \
-        } else {                                   \
-            second = fmin(second, sq);             \
-        }                                          \
-    }
-    ICM_CAND(xa.x, ya.x, ia.x)
-    ICM_CAND(xa.y, ya.y, ia.y)
-    ICM_CAND(xa.z, ya.z, ia.z)
-    ICM_CAND(xa.w, ya.w, ia.w)
-#undef ICM_CAND
-    if (n == 0) return -1;
-    if (n > kNeighCap || second <= best * (1.0 + 1e-15)) return assoc_grid_walk(g, gp, cx, cy, wx, wy, thr, thr2);
-    return (bid >= 0 && !(best > thr2)) ? bid : -1;
+    // (byte offset in 32 bits: the table has at most 2^25 cells, checked where it is sized -- a scalar base plus a
+    // 32-bit lane offset instead of 64-bit address arithmetic per beam)
+    const unsigned off = ((unsigned)cy * (unsigned)gp.nx + (unsigned)cx) << 7;
+    const char* __restrict__ r = reinterpret_cast<const char*>(g.nb) + off;
+    const double4 xa = *reinterpret_cast<const double4*>(r), ya = *reinterpret_cast<const double4*>(r + 32);
+    const int4 ia = *reinterpret_cast<const int4*>(r + 64);
+    const int n = *reinterpret_cast<const int*>(r + 80);
+    // squared distances to the (at most four) candidates; empty slots hold x = +inf
+    double dx = xa.x - wx, dy = ya.x - wy;
+    const double s0 = dx * dx + dy * dy;
+    dx = xa.y - wx; dy = ya.y - wy;
+    const double s1 = dx * dx + dy * dy;
+    dx = xa.z - wx; dy = ya.z - wy;
+    const double s2 = dx * dx + dy * dy;
+    dx = xa.w - wx; dy = ya.w - wy;
+    const double s3 = dx * dx + dy * dy;
+    // the nearest one and whether a second candidate is within a relative 1e-15 of it (then the reference's
+    // rule on the rounded sqrt decides: the range walk).  With no near tie exactly one c_i is set.
+    // (No early exit on an empty neighbourhood: every load of the record is in flight before anything is decided.)
+    const double best = fmin(fmin(s0, s1), fmin(s2, s3));
+    const double lim = best * (1.0 + 1e-15);
+    const bool c0 = s0 <= lim, c1 = s1 <= lim, c2 = s2 <= lim, c3 = s3 <= lim;
+    const bool tie = (c0 & (c1 | c2 | c3)) | (c1 & (c2 | c3)) | (c2 & c3);
+    const int bid = c0 ? ia.x : (c1 ? ia.y : (c2 ? ia.z : ia.w));
+    int lab = ((c0 | c1 | c2 | c3) & (bid >= 0) & !(best > thr2)) ? bid : -1;   // (no c_i: a non-finite point)
+    if (__builtin_expect((n > kNeighCap) | ((n != 0) & tie), 0)) lab = assoc_grid_walk(g, gp, cx, cy, wx, wy, thr, thr2);
+    return n == 0 ? -1 : lab;
 }
 
 // Fills the neighbourhood records of every cell of the current grid (one thread per cell;
@@ -658,7 +659,9 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (tl >= nloc) return;
     PoseTable<HS>& T = tables[wave_in_block()];
-    const int j0 = boff[tl], j1 = boff[tl + 1];
+    // (wave-uniform values through scalar registers: the pose's beam range becomes a scalar base pointer plus a
+    // 32-bit lane offset)
+    const int j0 = __builtin_amdgcn_readfirstlane(boff[tl]), j1 = __builtin_amdgcn_readfirstlane(boff[tl + 1]);
     if (j0 == j1) {
         if (lane == 0) {
             nent_out[tl] = 0;
@@ -666,6 +669,9 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         }
         return;
     }
+    const double* __restrict__ bxp = bx + j0;
+    const double* __restrict__ byp = by + j0;
+    const unsigned nbeam = (unsigned)(j1 - j0);
     for (int s = lane; s < kHash; s += kWave) {
         T.key[s] = kEmpty;
         T.cnt[s] = 0;
@@ -685,15 +691,26 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     int nent = 0;
     bool overflow = false;
     __builtin_amdgcn_wave_barrier();
+    // body points of the next 64 beams are requested one iteration ahead (unconditional loads at a clamped
+    // index, so that the wait in front of their use counts exactly them): a pose's batches no longer pay the
+    // latency of this load and of the grid record's one after the other
+    // (explicit 32-bit byte offsets: a pose has far fewer than 2^29 beams)
+    auto beam_at = [](const double* __restrict__ base, unsigned idx) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
+    };
+    double nbx = beam_at(bxp, min((unsigned)lane, nbeam - 1u)), nby = beam_at(byp, min((unsigned)lane, nbeam - 1u));
     for (int base = j0; base < j1 && !overflow; base += kWave) {
         const int j = base + lane;
         const bool valid = j < j1;
         const int cn = min(kWave, j1 - base);
         int lab = -2;
-        double bxx = 0.0, byy = 0.0;
+        const double bxx = valid ? nbx : 0.0, byy = valid ? nby : 0.0;
+        {
+            const unsigned on = min((unsigned)(j - j0) + (unsigned)kWave, nbeam - 1u);
+            nbx = beam_at(bxp, on);
+            nby = beam_at(byp, on);
+        }
         if (valid) {
-            bxx = bx[j];
-            byy = by[j];
             if (PRELABEL) {
                 lab = label[j];
             } else {
