@@ -625,6 +625,20 @@ __device__ __forceinline__ void seg_step(bool take, double& ax, double& ay) {
     }
 }
 
+// The same step across rows (row_bcast): `take` is false in every lane the move does not write, whose operand is
+// then whatever the register held.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step_rows(bool take, double& ax, double& ay) {
+    const int xl = __builtin_amdgcn_update_dpp(__double2loint(ax), __double2loint(ax), CTRL, ROW_MASK, 0xF, false);
+    const int xh = __builtin_amdgcn_update_dpp(__double2hiint(ax), __double2hiint(ax), CTRL, ROW_MASK, 0xF, false);
+    const int yl = __builtin_amdgcn_update_dpp(__double2loint(ay), __double2loint(ay), CTRL, ROW_MASK, 0xF, false);
+    const int yh = __builtin_amdgcn_update_dpp(__double2hiint(ay), __double2hiint(ay), CTRL, ROW_MASK, 0xF, false);
+    if (take) {
+        ax += __hiloint2double(xh, xl);
+        ay += __hiloint2double(yh, yl);
+    }
+}
+
 // HS = hash slots per pose; at most 3/4 of them may be used (distinct landmarks of one scan).
 // HS = 128 keeps the kernel at 14 KB of LDS and 64 VGPRs = 8 waves per SIMD (the kernel waits
 // on memory 2/3 of the time, so occupancy matters); a scan that overflows it makes the host
@@ -704,7 +718,7 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         const bool valid = j < j1;
         const int cn = min(kWave, j1 - base);
         int lab = -2;
-        const double bxx = valid ? nbx : 0.0, byy = valid ? nby : 0.0;
+        const double bxx = nbx, byy = nby;   // (lanes beyond the pose's last beam hold a copy of it: never a head or a tail, read by nobody)
         {
             const unsigned on = min((unsigned)(j - j0) + (unsigned)kWave, nbeam - 1u);
             nbx = beam_at(bxp, on);
@@ -734,8 +748,10 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         seg_step<0x112, 0xF>(dist >= 2, ax, ay);
         seg_step<0x114, 0xF>(dist >= 4, ax, ay);
         if (__ballot(dist >= 8) != 0ull) seg_step<0x118, 0xF>(dist >= 8, ax, ay);   // (wave-uniform skip)
-        seg_step<0x142, 0xA>(dist > (lane & 15), ax, ay);   // run began in an earlier row
-        seg_step<0x143, 0xC>(dist > (lane & 31), ax, ay);   // run began in rows 0-1
+        // across rows: rows 1 and 3 take lane 15 / 47 (row_bcast:15), rows 2 and 3 take lane 31 (row_bcast:31); the
+        // predicate names the receiving rows itself, so the lanes the DPP move leaves alone need no preset zero
+        seg_step_rows<0x142, 0xA>(((lane & 16) != 0) & (dist > (lane & 15)), ax, ay);   // run began in an earlier row
+        seg_step_rows<0x143, 0xC>((lane >= 32) & (dist > (lane & 31)), ax, ay);          // run began in rows 0-1
         const int nexthead = dpp_mov_i<0x130, 0xF>(head ? 1 : 0);   // wave_shl:1 (lane 63 reads 0): no LDS round trip
         bool tail = valid && (lane == cn - 1 || nexthead);
         // run tails claim / find the slot of their label
