@@ -17,9 +17,6 @@ constexpr int kWave = 64;
 // 1 only in eval_probe.hip (tools/count_eval_flops.py): the rarely taken slow paths (fmod in
 // wrap_pi, generic sincos beyond |d| = 0.25) are compiled out so that the probe's ISA is the
 // straight-line path an energy evaluation executes with the default isotropic Q.
-#ifndef ICM_EXPERIMENT_FOLD_ONLY
-#define ICM_EXPERIMENT_FOLD_ONLY 0
-#endif
 #ifndef ICM_PROBE_FAST_TRIG_ONLY
 #define ICM_PROBE_FAST_TRIG_ONLY 0
 #endif
@@ -400,7 +397,7 @@ __device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const P
                                                       double py, double th) {
     const double dl = th - f.tho;
     double e = pose_energy_folded(f, px, py, dl);
-    if (ICM_PROBE_FAST_TRIG_ONLY || ICM_EXPERIMENT_FOLD_ONLY) return e;
+    if (ICM_PROBE_FAST_TRIG_ONLY) return e;
     const bool folded = fabs(dl) <= f.dlim;
 #ifdef ICM_WAVE_TS
     {
