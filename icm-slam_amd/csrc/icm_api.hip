@@ -977,8 +977,8 @@ int icm_sweep_targets(icm_handle* h) {
 // even waves that deferred, on stream st.
 static int launch_fused_solve(icm_handle* h, const SolveArgs& a, SolveSeg g, hipStream_t st) {
     const int64_t npc = (g.t1 - g.t0) / 2 + 1;   // poses per colour (upper bound)
-    const bool quad = h->solve_quad == 1 || (h->solve_quad < 0 && npc * 4 <= (int64_t)1024 * kWave);
-    const int ppw = quad ? kWave / 4 : kWave;
+    const bool quad = h->solve_quad == 1;   // (automatic = one lane per pose: see icm_sweep_solve)
+    const int ppw = quad ? kWave / 4 : kWave;   // (fewer poses per lane-form wave was measured: 32 at S1 -8 %, 2 at 600 poses +38 %: not adopted)
     const int nwv = (int)((npc + ppw - 1) / ppw);
     if (h->solve_flag_waves < nwv) {
         HIPCHK(h, hipStreamSynchronize(h->stream));   // (re-allocation: nothing may still be polling the old flags)
@@ -1043,7 +1043,11 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
                 // per pose evaluating the four candidate points of an iteration at once -- used when
                 // a colour has too few poses to fill the chip's 1024 SIMDs even at 16 poses per wave
                 // (small sequences, small shards), where only the length of the serial chain counts.
-                const bool quad = h->solve_quad == 1 || (h->solve_quad < 0 && (int64_t)nw * 4 <= (int64_t)1024 * kWave);
+                // With the folded energy an evaluation is a sixth of an iteration's instructions, so the quad's
+                // one-evaluation iteration no longer pays for its broadcasts: the lane form is faster at every
+                // size measured (S1: 0.122 against 0.157 ms, 600 poses: 0.099 against 0.115) and is the
+                // automatic choice; the quad form stays selectable (icm_set_solve_lanes) and bit-identical.
+                const bool quad = h->solve_quad == 1;
                 if (quad) TIMED(h, KID_SOLVE, (k_solve_mq_colour<<<nblocks_threads((int64_t)nw * 4), kBlock, 0, h->stream>>>(a, col)));
                 else TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_waves((nw + kWave - 1) / kWave), kBlock, 0, h->stream>>>(a, col)));
             }
