@@ -821,11 +821,11 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         const bool occ = k != kEmpty;
         const unsigned long long mask = __ballot(occ);
         if (occ) {
-            const int q = written + prefix_count(mask, lane);
-            st_label[j0 + q] = k;
-            st_k[j0 + q] = T.cnt[s];
-            st_sbx[j0 + q] = T.sx[s];
-            st_sby[j0 + q] = T.sy[s];
+            const unsigned q = (unsigned)(written + prefix_count(mask, lane));   // (scalar bases + 32-bit offsets, like the beam loads)
+            *reinterpret_cast<int*>(reinterpret_cast<char*>(st_label + j0) + (q << 2)) = k;
+            *reinterpret_cast<int*>(reinterpret_cast<char*>(st_k + j0) + (q << 2)) = T.cnt[s];
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sbx + j0) + (q << 3)) = T.sx[s];
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sby + j0) + (q << 3)) = T.sy[s];
             isnew |= k == -1;
             if (DEBUG) T.owner[s] = q;
         }
