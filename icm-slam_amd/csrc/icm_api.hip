@@ -168,6 +168,7 @@ struct icm_handle {
     // A/B of the other on the main stream.
     hipStream_t solve_stream = nullptr;
     hipEvent_t ev_m[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};   // moments ready / solves done, per segment
+    bool rot_valid = false;          // rot[] holds (cos, sin)(theta - pi/2) of the current poses (written by the solves; k_pose_rot otherwise)
     bool solves_in_flight = false;   // ev_s[] are recorded and the main stream has not joined them yet
     int pipeline = 0;                // icm_set_pipeline (off by default: measured slower than one stream)
     bool pipe_ok = true;             // cleared by a table overflow until the next icm_set_state
@@ -608,6 +609,7 @@ static int set_state_impl(icm_handle* h, const double* x, const double* x0, cons
         if (rc) return rc;
     }
     h->have_state = true;
+    h->rot_valid = false;
     h->hier_ok = true;
     h->pipe_ok = true;
     if (wait_host) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -684,6 +686,7 @@ int icm_bind_pose_buffer(icm_handle* h, void* x_dev) {
     if (!x_dev) FAIL(h, ICM_ERR_ARG, "icm_bind_pose_buffer: null buffer");
     h->x = reinterpret_cast<double*>(x_dev);
     h->x_external = true;
+    h->rot_valid = false;
     return ICM_OK;
 }
 
@@ -814,7 +817,10 @@ int icm_sweep_local(icm_handle* h) {
         h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
         h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p)))
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
-    TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p)));
+    if (!h->rot_valid) {   // (the poses came from the host, a snapshot or a solve form that does not keep the table)
+        TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p)));
+        h->rot_valid = true;
+    }
     if (h->brute)
         TIMED(h, KID_ASSOC_BRUTE, (k_associate_brute<<<nbw, kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, h->mapx.p, h->mapy.p, km, h->cfg.dist_thr, h->label.p)));
     const int ntiles = (nloc + kScanTile - 1) / kScanTile;
@@ -1023,6 +1029,10 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         if (fresh) HIPCHK(h, hipMemsetAsync(h->diag.p, 0, 3 * (size_t)h->T * sizeof(double), h->stream));
     }
     a.diag = h->debug ? h->diag.p : nullptr;
+    // the moment-form solves write the rotation table entry of every pose they write (store_pose): after both colours
+    // the next sweep needs no k_pose_rot launch
+    a.rot = h->form == 0 ? h->rot.p : nullptr;
+    if (h->form != 0) h->rot_valid = false;   // (the cross-check forms do not keep it)
     if (schedule == ICM_SCHEDULE_SEQUENTIAL) {
         if (h->world != 1) FAIL(h, ICM_ERR_UNSUPPORTED, "the sequential (reference-order) schedule is one dependent chain and cannot be sharded");
         if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
@@ -1199,6 +1209,7 @@ int icm_restore_state(icm_handle* h) {
     { int rcj = join_solves(h); if (rcj) return rcj; }
     hipStream_t st = h->stream;   // stream-ordered behind the last sweep: no synchronisation needed
     HIPCHK(h, hipMemcpyAsync(h->x, sn.x.p, 3 * T * sizeof(double), hipMemcpyDeviceToDevice, st));
+    h->rot_valid = false;
     HIPCHK(h, hipMemcpyAsync(h->mapx.p, sn.mapx.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->mapy.p, sn.mapy.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->counts_new.p, sn.counts_new.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1222,6 +1233,7 @@ static SolveArgs solve_args(icm_handle* h) {
     a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
     a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
     a.diag = nullptr;
+    a.rot = h->rot.p;
     return a;
 }
 

@@ -1921,7 +1921,28 @@ struct SolveArgs {
     const double *pose_c, *pose_m;
     double dt, R0, R1, R2, Q0, Q1, cte;
     double* diag;         // optional (T,3): f, nit, nfev per pose
+    double* rot;          // optional (nloc,2): (cos, sin)(theta - pi/2) of the solved pose, the table phase A and the
+                          // moment kernel of the NEXT sweep read (k_pose_rot's values: whoever writes a pose writes its pair)
 };
+
+// Result of one pose solve -> x (write-through when other waves of the same launch wait for it) and the rotation table.
+__device__ __forceinline__ void store_pose(const SolveArgs& a, int tg, const double res[3], bool publish) {
+    if (publish) {
+        __hip_atomic_store(&a.x[3 * (size_t)tg], res[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.x[3 * (size_t)tg + 1], res[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.x[3 * (size_t)tg + 2], res[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        a.x[3 * (size_t)tg] = res[0];
+        a.x[3 * (size_t)tg + 1] = res[1];
+        a.x[3 * (size_t)tg + 2] = res[2];
+    }
+    if (a.rot) {
+        double ct, st;
+        pose_rot(res[2], ct, st);
+        a.rot[2 * (size_t)(tg - a.t_begin)] = ct;
+        a.rot[2 * (size_t)(tg - a.t_begin) + 1] = st;
+    }
+}
 
 __device__ __forceinline__ void load3(const double* __restrict__ a, int T, int t, double o[3]) {
     o[0] = a[t]; o[1] = a[(size_t)T + t]; o[2] = a[2 * (size_t)T + t];
@@ -2173,9 +2194,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
     double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
     double res[3];
     solve_pose_moments<false>(a, tg, prev, res);
-    a.x[3 * (size_t)tg] = res[0];
-    a.x[3 * (size_t)tg + 1] = res[1];
-    a.x[3 * (size_t)tg + 2] = res[2];
+    store_pose(a, tg, res, false);
 }
 
 // Both half sweeps of an unsharded red-black sweep in ONE launch.  An even pose reads only its
@@ -2219,17 +2238,8 @@ __device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, const Solve
         double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
         double res[3];
         solve_pose_moments<QUAD>(a, tg, prev, res, role);
-        if (role == 0) {
-            if (!even) {   // handed to the even waves of this launch: write-through (sc1) stores, no cache-wide release needed
-                __hip_atomic_store(&a.x[3 * (size_t)tg], res[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.x[3 * (size_t)tg + 1], res[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.x[3 * (size_t)tg + 2], res[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                a.x[3 * (size_t)tg] = res[0];
-                a.x[3 * (size_t)tg + 1] = res[1];
-                a.x[3 * (size_t)tg + 2] = res[2];
-            }
-        }
+        // (odd poses are handed to the even waves of this launch: write-through (sc1) stores, no cache-wide release needed)
+        if (role == 0) store_pose(a, tg, res, !even);
     }
 }
 
@@ -2308,11 +2318,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, int col
     double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
     double res[3];
     solve_pose_moments<true>(a, tg, prev, res, role);
-    if (role == 0) {
-        a.x[3 * (size_t)tg] = res[0];
-        a.x[3 * (size_t)tg + 1] = res[1];
-        a.x[3 * (size_t)tg + 2] = res[2];
-    }
+    if (role == 0) store_pose(a, tg, res, false);
 }
 
 // Reference order, moment form: one DPP quad walks the chain t = 1..T-1 (latency form of the
@@ -2324,11 +2330,7 @@ __global__ __launch_bounds__(kWave) void k_solve_m_sequential(SolveArgs a) {
     for (int tg = 1; tg < a.T; ++tg) {
         double res[3];
         solve_pose_moments<true>(a, tg, prev, res, role);
-        if (role == 0) {
-            a.x[3 * (size_t)tg] = res[0];
-            a.x[3 * (size_t)tg + 1] = res[1];
-            a.x[3 * (size_t)tg + 2] = res[2];
-        }
+        if (role == 0) store_pose(a, tg, res, false);
         prev[0] = res[0]; prev[1] = res[1]; prev[2] = res[2];
     }
 }
