@@ -15,7 +15,7 @@ for name, n in (("S1", 4000), ("S2", 3000)):
         if i and i % 12 == 0:
             if i == 12:
                 ref = eng.get_state()
-            elif i % 1200 == 0:
+            elif i % 60 == 0:
                 cur = eng.get_state()
                 assert all(np.array_equal(a, b) for a, b in zip(ref, cur)), "state after 12 sweeps differs from the first round"
             eng.restore_state()
