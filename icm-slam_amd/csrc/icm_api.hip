@@ -856,7 +856,7 @@ int icm_sweep_local(icm_handle* h) {
                 h->nchunks, h->chunk_group, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
                 h->rec_off.p, h->rec_off.p + nrec, h->rec_off.p + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->flags.p)));
             double* stats_mine = h->world > 1 ? stats_slot(h) : nullptr;
-            TIMED(h, KID_LM_L3, (k_lm_l3<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, h->new_rank.p + nloc, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p, h->ent_off.p + nloc, h->flags.p)));
+            TIMED(h, KID_LM_L3, (k_lm_l3<<<(L + kWave - 1) / kWave, kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, h->new_rank.p + nloc, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p, h->ent_off.p + nloc, h->flags.p)));
         }
         if (hier) {  // k_lm_l3 gathered the four words
             HIPCHK(h, hipMemcpyAsync(h->pin_i, h->flags.p + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1244,7 +1244,8 @@ static SolveArgs solve_args(icm_handle* h) {
 // (k_solve_m_fused, SolveSeg).  0 = the sequence is too short to cut.
 static int pipeline_split_super(const icm_handle* h) {
     if (h->nsuper < 2) return 0;
-    const int s = h->nsuper / 2;
+    const int s = (h->nsuper / 2) / kL3Rows * kL3Rows;   // (a whole number of k_lm_l3's row groups: same additions as unsegmented)
+    if (s == 0) return 0;
     const int64_t M = (int64_t)s * h->chunk_group * h->chunk_poses;
     return (M >= 2 && M + 1 < h->nloc) ? s : 0;
 }
@@ -1337,7 +1338,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
 #undef CHUNK_L1
         k_chunk_l2<<<s1 - s0, kT1, 0, X>>>(NC, G, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
                                            ro, ro + nrec, ro + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->flags.p, s0, 1);
-        k_lm_l3<<<nblocks_threads(L), kBlock, 0, X>>>(S, L, h->lact0, h->new_rank.p + t1, ms, ms + msn, ms + 2 * msn, nullptr,
+        k_lm_l3<<<(L + kWave - 1) / kWave, kBlock, 0, X>>>(S, L, h->lact0, h->new_rank.p + t1, ms, ms + msn, ms + 2 * msn, nullptr,
                                                       h->y_raw.p, h->cnt_raw.p, h->ent_off.p + t1, h->flags.p, s0, s1,
                                                       seg ? h->l3_carry.p : nullptr, seg ? nullptr : h->l3_carry.p, seg);
         if (seg) HIPCHK(h, hipEventRecord(h->ev_map, X));   // raw map, counts and flags are final: the copy stream takes them from here

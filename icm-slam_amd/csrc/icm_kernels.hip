@@ -1368,6 +1368,11 @@ __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, con
 // A sweep may take the rows in consecutive ranges (time segments): carry_in = the column sums of the
 // rows before (null: none), carry_out = those through row_end (null: not needed).  final: the totals
 // go out -- stats != nullptr: the rank's totals for the exchange [sx(L) | sy(L) | n(L)]; else the raw map.
+// Mapping: a workgroup takes 64 columns; its four waves take sixteen rows each -- every thread has its
+// (at most kMaxSuper / 4) rows in flight at once, prefixes them locally, and the groups' totals meet in LDS.  (One
+// thread per column walking all rows, eight loads at a time, took 20 us for 30 MB: 157 waves cannot keep HBM busy.)
+constexpr int kL3Groups = kBlock / kWave;                                   // row groups = waves of a workgroup
+constexpr int kL3Rows = (kMaxSuper + kL3Groups - 1) / kL3Groups;            // rows per group (upper bound)
 __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, const int* __restrict__ n_new_dev,
                                                   double* __restrict__ ms_x, double* __restrict__ ms_y,
                                                   double* __restrict__ ms_n, double* __restrict__ stats,
@@ -1375,47 +1380,67 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
                                                   const int* __restrict__ n_ent_dev, int* __restrict__ flags,
                                                   int row_begin = 0, int row_end = -1, const double* __restrict__ carry_in = nullptr,
                                                   double* __restrict__ carry_out = nullptr, int final = 1) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ double tot[3][kL3Groups][kWave];
+    const int col = threadIdx.x & (kWave - 1), grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * kWave + col;
     if (row_end < 0) row_end = nsuper;
-    if (i == 0 && final) {  // what the host reads back at its one synchronisation of the sweep, in one 16-byte copy
+    if (blockIdx.x == 0 && threadIdx.x == 0 && final) {  // what the host reads back at its one synchronisation of the sweep, in one 16-byte copy
         flags[4] = *n_ent_dev;
         flags[5] = *n_new_dev;
         flags[6] = flags[0];
         flags[7] = flags[1];
         flags[2] = lact0 + *n_new_dev > L ? 1 : 0;   // labels beyond the map capacity (the reference's IndexError)
     }
-    if (i >= L) return;
-    double ax = 0.0, ay = 0.0, an = 0.0;
-    if (carry_in) {
+    // groups are ABSOLUTE row ranges [16 g, 16 g + 16): a sweep that takes the rows in two ranges (cut at a multiple of
+    // kL3Rows: pipeline_split_super) adds every column up in the same association as one that takes them at once
+    const int r0 = max(grp * kL3Rows, row_begin), r1 = max(min((grp + 1) * kL3Rows, row_end), r0);
+    const bool live = i < L && i < lact0 + *n_new_dev;          // columns of labels that do not exist are all zero
+    double vx[kL3Rows], vy[kL3Rows], vn[kL3Rows];
+    double tx = 0.0, ty = 0.0, tn = 0.0;
+    if (live) {
+#pragma unroll
+        for (int b = 0; b < kL3Rows; ++b) {   // all loads first (clamped row: unused values are never added)
+            const size_t q = (size_t)min(r0 + b, max(row_end - 1, row_begin)) * L + i;
+            vx[b] = ms_x[q];
+            vy[b] = ms_y[q];
+            vn[b] = ms_n[q];
+        }
+#pragma unroll
+        for (int b = 0; b < kL3Rows; ++b) {   // exclusive prefix inside the group, in place
+            const bool on = r0 + b < r1;
+            const double x_ = vx[b], y_ = vy[b], n_ = vn[b];
+            vx[b] = tx; vy[b] = ty; vn[b] = tn;
+            if (on) { tx += x_; ty += y_; tn += n_; }
+        }
+    }
+    tot[0][grp][col] = tx;
+    tot[1][grp][col] = ty;
+    tot[2][grp][col] = tn;
+    __syncthreads();
+    double ax = 0.0, ay = 0.0, an = 0.0;   // sums before this group's rows: the carry and the groups before
+    if (carry_in && i < L) {
         ax = carry_in[i];
         ay = carry_in[L + i];
         an = carry_in[2 * (size_t)L + i];
     }
-    if (i < lact0 + *n_new_dev) {  // columns of labels that do not exist are all zero
-        constexpr int kBatch = 8;   // loads of a batch are issued together, then the stores
-        for (int s0 = row_begin; s0 < row_end; s0 += kBatch) {
-            double vx[kBatch], vy[kBatch], vn[kBatch];
+    for (int g2 = 0; g2 < grp; ++g2) {
+        ax += tot[0][g2][col];
+        ay += tot[1][g2][col];
+        an += tot[2][g2][col];
+    }
+    if (live) {
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
-                const size_t q = (size_t)min(s0 + b, row_end - 1) * L + i;
-                vx[b] = ms_x[q];
-                vy[b] = ms_y[q];
-                vn[b] = ms_n[q];
-            }
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
-                if (s0 + b < row_end) {
-                    const size_t q = (size_t)(s0 + b) * L + i;
-                    ms_x[q] = ax;
-                    ms_y[q] = ay;
-                    ms_n[q] = an;
-                    ax += vx[b];
-                    ay += vy[b];
-                    an += vn[b];
-                }
+        for (int b = 0; b < kL3Rows; ++b) {
+            if (r0 + b < r1) {
+                const size_t q = (size_t)(r0 + b) * L + i;
+                ms_x[q] = ax + vx[b];
+                ms_y[q] = ay + vy[b];
+                ms_n[q] = an + vn[b];
             }
         }
     }
+    if (grp != kL3Groups - 1 || i >= L) return;   // the last group holds the column totals
+    ax += tx; ay += ty; an += tn;
     if (carry_out) {
         carry_out[i] = ax;
         carry_out[L + i] = ay;
