@@ -236,12 +236,15 @@ struct RcclApi {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 } g_rccl;
 
+std::string g_rccl_path;   // icm_comm_set_library: the copy to load when none is loaded yet
+
 bool rccl_load(std::string& err) {
     if (g_rccl.lib) return true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     void* lib = nullptr;
     for (const char* n : names)   // already loaded by the host application?
         if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!lib && !g_rccl_path.empty()) lib = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_GLOBAL);
     if (!lib)
         for (const char* n : names)
             if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
@@ -1428,6 +1431,11 @@ int icm_get_pipeline_used(const icm_handle* h) { return h ? h->pipe_used : ICM_E
             return ICM_ERR_HIP;                                                                              \
         }                                                                                                    \
     } while (0)
+
+int icm_comm_set_library(const char* path) {
+    g_rccl_path = path ? path : "";
+    return ICM_OK;
+}
 
 int icm_comm_available(void) {
     std::string err;

@@ -49,6 +49,7 @@ SIGNATURES = {
     "icm_halo_unpack": (C.c_int, [_H]),
     "icm_bind_pose_buffer": (C.c_int, [_H, C.c_void_p]),
     "icm_pose_buffer": (C.c_void_p, [_H]),
+    "icm_comm_set_library": (C.c_int, [C.c_char_p]),
     "icm_comm_available": (C.c_int, []),
     "icm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "icm_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
@@ -97,6 +98,22 @@ SIGNATURES = {
 _lib = None
 
 
+def _torch_lib(name):
+    """Path of a library a PyTorch-ROCm wheel bundles (None if there is no such wheel / file); torch is not imported."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    for d in spec.submodule_search_locations:
+        cand = os.path.join(d, "lib", name)
+        if os.path.exists(cand):
+            return cand
+    return None
+
+
 def _preload_torch_hip_runtime():
     """PyTorch-ROCm wheels bundle their own libamdhip64.so.  A process must use ONE HIP
     runtime: if ours (the system ROCm) were loaded first, a later `import torch` would find
@@ -136,6 +153,11 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # same for RCCL, but lazily: the library dlopen()s it only when collectives are asked for, and then takes the
+    # wheel's copy unless the process has one loaded already (two copies in one process crash at exit)
+    rccl = _torch_lib("librccl.so")
+    if rccl:
+        lib.icm_comm_set_library(rccl.encode())
     _lib = lib
     return lib
 

@@ -149,6 +149,8 @@ void *icm_pose_buffer(icm_handle *h);                 /* device pointer of x (T,
  * one whole red-black sweep -- phase A, all-gather of the statistics, targets, odd poses, all-gather
  * of the halos, even poses, Mapa.filtrar -- with both collectives on the handle's stream;
  * icm_gather_poses all-gathers the pose blocks before icm_get_state. */
+int icm_comm_set_library(const char *path);           /* the RCCL copy to load if the process has none loaded yet
+                                                          (a process must use ONE: e.g. the copy a PyTorch wheel bundles) */
 int icm_comm_available(void);                         /* 1 when an RCCL library can be resolved */
 int icm_comm_unique_id(void *id128);
 int icm_comm_init(icm_handle *h, const void *id128, int rank, int world);

@@ -23,6 +23,15 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.icm_version()
 
 
+def test_library_collectives_entry_points_without_a_gpu():
+    """The entry points of the library-issued collectives refuse a null handle without resolving RCCL or touching a
+    device (RCCL itself is only dlopen()ed when a communicator is asked for: tests/test_gpu_sharded.py)."""
+    from icmslam_hip import _lib
+    lib = _lib.load()
+    assert lib.icm_sweep_sharded(None) != 0 and lib.icm_gather_poses(None) != 0
+    assert lib.icm_comm_init(None, None, 0, 1) != 0 and lib.icm_comm_destroy(None) != 0
+
+
 def test_create_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
