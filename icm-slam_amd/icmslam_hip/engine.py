@@ -312,16 +312,28 @@ class SweepEngine:
         return self.lib.icm_pose_buffer(self.h)
 
     # ---- collectives issued by the library (RCCL on the handle's stream) ---------------------
+    @staticmethod
+    def _torch_before_rccl():
+        """Where a PyTorch-ROCm wheel is installed, import it BEFORE the library dlopen()s RCCL: the wheel's RCCL
+        loaded ahead of the rest of the wheel tears down in the wrong order at interpreter exit (glibc reports a
+        double free).  Processes without torch are not affected."""
+        import sys
+        if "torch" not in sys.modules and _lib._torch_lib("librccl.so"):
+            import torch  # noqa: F401
+
     def comm_available(self):
+        self._torch_before_rccl()
         return bool(self.lib.icm_comm_available())
 
     def comm_unique_id(self):
         """128-byte RCCL id (rank 0 makes it, every rank passes it to comm_init)."""
+        self._torch_before_rccl()
         buf = (C.c_ubyte * 128)()
         self._chk(self.lib.icm_comm_unique_id(C.cast(buf, C.c_void_p)))
         return bytes(buf)
 
     def comm_init(self, id128, rank, world):
+        self._torch_before_rccl()
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
         self._chk(self.lib.icm_comm_init(self.h, C.cast(buf, C.c_void_p), int(rank), int(world)))
 
