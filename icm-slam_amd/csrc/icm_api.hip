@@ -172,6 +172,10 @@ struct icm_handle {
     bool solves_in_flight = false;   // ev_s[] are recorded and the main stream has not joined them yet
     int pipeline = 0;                // icm_set_pipeline (off by default: measured slower than one stream)
     bool pipe_ok = true;             // cleared by a table overflow until the next icm_set_state
+    // Optimistic sweep (icm_sweep_classic): the whole sweep is queued without the host looking at phase A's counts
+    // and overflow flags in the middle; the kernels that would replace state (solves, Mapa.filtrar) look at the
+    // flags themselves, the host reads them with the filtrar result and repeats the sweep the careful way if set.
+    bool optimistic = false;
     int pipe_used = 0;               // the last sweep ran pipelined
     DevBuf<double> x_bak, l3_carry;
     DevBuf<double> rot;   // (cos, sin)(theta - pi/2) per pose of the shard, refreshed at the start of every sweep (k_pose_rot)
@@ -211,6 +215,7 @@ struct icm_handle {
         }                                                                      \
     } while (0)
 
+constexpr int kRetryCareful = 1000;   // (internal: icm_sweep_finish -> icm_sweep_classic, never returned to the caller)
 static inline int nblocks_waves(int64_t nwaves) { return (int)((nwaves + kWavesPerBlock - 1) / kWavesPerBlock); }
 static inline int nblocks_threads(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
@@ -868,6 +873,7 @@ int icm_sweep_local(icm_handle* h) {
             HIPCHK(h, hipMemcpyAsync(h->pin_i + 1, h->new_rank.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         }
+        if (h->optimistic && hier) break;   // (no host look here: icm_sweep_finish reads the four words)
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->pin_i[2] && h->hash_slots == 128) {  // a scan with > 96 distinct landmarks: use the larger table from now on
             h->hash_slots = 256;
@@ -878,6 +884,11 @@ int icm_sweep_local(icm_handle* h) {
     }
 #undef ASSOC_GROUP_HS
 #undef ASSOC_GROUP
+    if (h->optimistic && hier) {
+        h->path_used = 1;
+        HIPCHK(h, hipGetLastError());
+        return ICM_OK;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->E = h->pin_i[0];
     h->n_new_loc = h->pin_i[1];
@@ -965,7 +976,7 @@ int icm_sweep_targets(icm_handle* h) {
             HIPCHK(h, hipMemcpyAsync(h->pin_d + 3 * Ls + 16 + r, h->stats_all + (size_t)r * (size_t)icm_stats_stride(h) + 3 * Ls, sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
     if (h->gpu_filtrar) {
         hipStream_t fs = h->timing ? h->stream : h->copy_stream;   // (timing: serialised on the main stream so that the events bracket it)
-        int rc = launch_filtrar(h, fs);
+        int rc = launch_filtrar(h, fs, h->optimistic);
         if (rc) return rc;
         if (h->timing) {
             HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
@@ -1043,7 +1054,7 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         else TIMED(h, KID_SOLVE, (k_solve_m_sequential<<<1, kWave, 0, h->stream>>>(a)));
     } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->world == 1 && h->t_begin == 0 && h->form == 0 && h->fuse_colours) {
         // both colours of an unsharded sweep in one launch, even waves chase the odd ones
-        int rc = launch_fused_solve(h, a, SolveSeg{0, (int)h->nloc, 0, nullptr}, h->stream);
+        int rc = launch_fused_solve(h, a, SolveSeg{0, (int)h->nloc, 0, h->optimistic ? h->flags.p : nullptr}, h->stream);
         if (rc) return rc;
     } else if (schedule == ICM_SCHEDULE_REDBLACK) {
         const int nw = (int)(h->nloc / 2 + 1);
@@ -1098,6 +1109,13 @@ int icm_sweep_finish(icm_handle* h) {
     if (!h->map_copy_pending) FAIL(h, ICM_ERR_ARG, "icm_sweep_finish: call icm_sweep_targets first");
     HIPCHK(h, hipEventSynchronize(h->ev_copied));  // the solves may still be running
     h->map_copy_pending = false;
+    if (h->optimistic) {   // phase A's counts and flags, read only now (the copy was queued behind k_lm_l3)
+        h->E = h->pin_i[0];
+        h->n_new_loc = h->pin_i[1];
+        if (h->pin_i[2] || (h->pin_i[3] & 1)) return kRetryCareful;   // a table overflowed: poses and map were left alone
+        if ((int64_t)h->lact0 + h->n_new_loc > (int64_t)L)
+            FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
+    }
     // total number of landmarks created this sweep, over all ranks
     int64_t n_new = h->n_new_loc;
     if (h->world > 1) {
@@ -1259,13 +1277,29 @@ static bool pipeline_applies(const icm_handle* h, int schedule) {
            h->hier_ok && h->gpu_filtrar && !h->x_external && pipeline_split_super(h) > 0;
 }
 
+// The sweep can be queued whole, without a host look at phase A's outcome in the middle: an unsharded red-black
+// sweep through the hierarchical pipeline, the one-launch solve and Mapa.filtrar on the device (the kernels that
+// would replace state check the sweep's flags themselves).  Not while per-kernel timing serialises the streams.
+static bool optimistic_applies(const icm_handle* h, int schedule) {
+    return schedule == ICM_SCHEDULE_REDBLACK && h->world == 1 && h->t_begin == 0 && h->form == 0 && h->fuse_colours &&
+           h->entry_path != 0 && h->hier_ok && !h->debug && !h->per_beam && !h->brute && h->gpu_filtrar && !h->timing;
+}
+
 static int icm_sweep_classic(icm_handle* h, int schedule) {
-    int rc;
     h->pipe_used = 0;
-    if ((rc = icm_sweep_local(h))) return rc;
-    if ((rc = icm_sweep_targets(h))) return rc;
-    if ((rc = icm_sweep_solve(h, schedule, -1))) return rc;
-    return icm_sweep_finish(h);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        h->optimistic = attempt == 0 && optimistic_applies(h, schedule);
+        int rc = icm_sweep_local(h);
+        if (!rc) rc = icm_sweep_targets(h);
+        if (!rc) rc = icm_sweep_solve(h, schedule, -1);
+        if (!rc) rc = icm_sweep_finish(h);
+        h->optimistic = false;
+        if (rc != kRetryCareful) return rc;
+        // a per-pose or per-chunk table overflowed: solves and Mapa.filtrar saw the flags and changed nothing;
+        // once more with the host looking in the middle (it sizes the tables / takes the sort-based pipeline)
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return ICM_OK;
 }
 
 // One red-black sweep with the two time segments software-pipelined over two streams:

@@ -174,6 +174,36 @@ def test_new_landmarks_beyond_capacity_raise_index_error(mode):
     eng.close()
 
 
+def test_sweep_queued_without_a_host_look_refuses_and_recovers_like_the_careful_one():
+    """The red-black sweep is queued whole (no host look at phase A's counts and flags in the middle; solves and
+    Mapa.filtrar check the flags on the device).  When the sweep would create more landmarks than the map holds, the
+    IndexError comes out at the end instead of the middle -- with the poses untouched and the handle usable: the same
+    state then sweeps to the same result as a fresh handle."""
+    from icmslam_hip import SweepEngine
+    zz, odo, u = dataset()
+    init = gold("init_pass.npz")
+    la = int(init["landmarks_actuales"])
+    eng = SweepEngine(Cfg(L=la + 5))          # sweep 1 of the dataset creates 67 landmarks
+    eng.upload(zz, odo, u)
+    eng.set_state(init["map_init"].copy(), init["x_init"].copy(), odo[:, 0], la)
+    with pytest.raises(IndexError):
+        eng.sweep_device("redblack")
+    x_after, m_after, c_after, K_after = eng.get_state()
+    assert np.array_equal(x_after, init["x_init"]) and K_after == la     # nothing was replaced
+    eng.close()
+    ref = SweepEngine(Cfg(L=la + 100))
+    ref.upload(zz, odo, u)
+    ref.set_state(init["map_init"].copy(), init["x_init"].copy(), odo[:, 0], la)
+    ref.sweep_device("redblack")
+    xr, mr, cr, Kr = ref.get_state()
+    ref.set_colour_fusion(False)              # the careful path (host look in the middle) on the same state
+    ref.set_state(init["map_init"].copy(), init["x_init"].copy(), odo[:, 0], la)
+    ref.sweep_device("redblack")
+    xc, mc, cc, Kc = ref.get_state()
+    ref.close()
+    assert Kr == Kc and np.array_equal(xr, xc) and np.array_equal(mr, mc) and np.array_equal(cr, cc)
+
+
 def test_sequence_shorter_than_one_chunk():
     """Fewer poses than one 64-pose chunk (and not a multiple of the group size)."""
     from icmslam_hip import SweepEngine
