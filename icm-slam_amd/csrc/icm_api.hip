@@ -175,7 +175,8 @@ struct icm_handle {
     // Optimistic sweep (icm_sweep_classic): the whole sweep is queued without the host looking at phase A's counts
     // and overflow flags in the middle; the kernels that would replace state (solves, Mapa.filtrar) look at the
     // flags themselves, the host reads them with the filtrar result and repeats the sweep the careful way if set.
-    bool optimistic = false;
+    bool optimistic = false;   // this sweep is queued whole (decided at its start, icm_sweep_local)
+    bool opt_req = false;      // asked for: by icm_sweep_classic for its first attempt, by icm_set_optimistic for the phase calls
     int pipe_used = 0;               // the last sweep ran pipelined
     DevBuf<double> x_bak, l3_carry;
     DevBuf<double> rot;   // (cos, sin)(theta - pi/2) per pose of the shard, refreshed at the start of every sweep (k_pose_rot)
@@ -215,7 +216,6 @@ struct icm_handle {
         }                                                                      \
     } while (0)
 
-constexpr int kRetryCareful = 1000;   // (internal: icm_sweep_finish -> icm_sweep_classic, never returned to the caller)
 static inline int nblocks_waves(int64_t nwaves) { return (int)((nwaves + kWavesPerBlock - 1) / kWavesPerBlock); }
 static inline int nblocks_threads(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
@@ -711,10 +711,13 @@ void* icm_pose_buffer(icm_handle* h) {
 // header of a rank's statistics message: [0] new landmarks, [1] flags, [2..4] first pose of the
 // shard, [5..7] last pose -- the boundary poses ride along, so the halo exchange that would
 // precede the next odd half sweep needs no collective of its own
-__global__ void k_set_header(double* stats, int L, double n_new, double flags, const double* __restrict__ x, int first, int last) {
+// n_new_dev / flags_dev (nullable): the values on the device, for a sweep queued without a host look at them
+// ([1] = 1 when one of this rank's tables overflowed or its labels exceed L: every rank then leaves state alone).
+__global__ void k_set_header(double* stats, int L, double n_new, double flags, const double* __restrict__ x, int first, int last,
+                             const int* __restrict__ n_new_dev = nullptr, const int* __restrict__ flags_dev = nullptr) {
     double* hd = stats + 3 * (size_t)L;
-    hd[0] = n_new;
-    hd[1] = flags;
+    hd[0] = n_new_dev ? (double)*n_new_dev : n_new;
+    hd[1] = flags_dev ? ((flags_dev[0] | flags_dev[1] | flags_dev[2]) ? 1.0 : 0.0) : flags;
     for (int i = 0; i < 3; ++i) {
         hd[2 + i] = x[3 * (size_t)first + i];
         hd[5 + i] = x[3 * (size_t)last + i];
@@ -798,12 +801,21 @@ static int launch_filtrar_merge(icm_handle* h, hipStream_t fs, int n) {
     return ICM_OK;
 }
 
+// A sweep can be queued whole, without a host look at phase A's outcome in the middle: a red-black sweep through the
+// hierarchical pipeline with the moment-form solves and Mapa.filtrar on the device -- the kernels that would replace
+// state check the sweep's flags themselves (sharded: every rank's flags travel in the header of its statistics).  Not
+// while per-kernel timing serialises the streams.
+static bool optimistic_applies(const icm_handle* h) {
+    return h->form == 0 && h->entry_path != 0 && h->hier_ok && !h->debug && !h->per_beam && !h->brute && h->gpu_filtrar && !h->timing;
+}
+
 // Phase A + local statistics.
 int icm_sweep_local(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_local: no state (icm_set_state)");
     HIPCHK(h, hipSetDevice(h->device));
     { int rcj = join_solves(h); if (rcj) return rcj; }
+    h->optimistic = h->opt_req && optimistic_applies(h);
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     // pose 0 without kept beams: the reference returns its inputs untouched
     // (scripts/ICM_ROS.py:133-135).  Every rank sees the same scan 0 only if it owns it; the
@@ -886,6 +898,8 @@ int icm_sweep_local(icm_handle* h) {
 #undef ASSOC_GROUP
     if (h->optimistic && hier) {
         h->path_used = 1;
+        if (h->world > 1)
+            k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, 0.0, 0.0, h->x, edge_first(h), edge_last(h), h->new_rank.p + nloc, h->flags.p);
         HIPCHK(h, hipGetLastError());
         return ICM_OK;
     }
@@ -946,7 +960,7 @@ int icm_sweep_targets(icm_handle* h) {
         const double* pre = reinterpret_cast<const double*>(h->e_w.p);
         double* ro = h->rec_off.p;
         if (h->world > 1)
-            TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
+            TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p, h->optimistic ? h->flags.p : nullptr)));
         TIMED(h, KID_REC_PUSH, (k_rec_push<<<nblocks_threads(nrec), kBlock, 0, h->stream>>>(
             nrec, h->chunk_group, L, h->rec_label.p, h->ms.p, h->ms.p + msn, h->ms.p + 2 * msn,
             h->world > 1 ? h->off_sx.p : nullptr, h->world > 1 ? h->off_sy.p : nullptr, h->world > 1 ? h->off_n.p : nullptr,
@@ -984,6 +998,8 @@ int icm_sweep_targets(icm_handle* h) {
         }
         HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
     }
+    if (h->optimistic)   // the sweep's flags as every rank sees them (k_stats_prefix folded the other ranks' in)
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 12, h->flags.p, 3 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
     if (h->path_used == 1) {  // next sweep's matrix: cleared here, under the solves (icm_sweep_finish waits for this stream)
         HIPCHK(h, hipMemsetAsync(h->ms.p, 0, 3 * (size_t)h->nsuper * (size_t)L * sizeof(double), h->copy_stream));
         h->ms_clean = true;
@@ -1042,6 +1058,8 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         HIPCHK(h, h->diag.reserve(3 * (size_t)h->T));
         if (fresh) HIPCHK(h, hipMemsetAsync(h->diag.p, 0, 3 * (size_t)h->T * sizeof(double), h->stream));
     }
+    if (h->optimistic && schedule != ICM_SCHEDULE_REDBLACK)
+        FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: a sweep queued without a host look (icm_set_optimistic) is a red-black sweep");
     a.diag = h->debug ? h->diag.p : nullptr;
     // the moment-form solves write the rotation table entry of every pose they write (store_pose): after both colours
     // the next sweep needs no k_pose_rot launch
@@ -1072,8 +1090,8 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
                 // size measured (S1: 0.122 against 0.157 ms, 600 poses: 0.099 against 0.115) and is the
                 // automatic choice; the quad form stays selectable (icm_set_solve_lanes) and bit-identical.
                 const bool quad = h->solve_quad == 1;
-                if (quad) TIMED(h, KID_SOLVE, (k_solve_mq_colour<<<nblocks_threads((int64_t)nw * 4), kBlock, 0, h->stream>>>(a, col)));
-                else TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_waves((nw + kWave - 1) / kWave), kBlock, 0, h->stream>>>(a, col)));
+                if (quad) TIMED(h, KID_SOLVE, (k_solve_mq_colour<<<nblocks_threads((int64_t)nw * 4), kBlock, 0, h->stream>>>(a, col, h->optimistic ? h->flags.p : nullptr)));
+                else TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_waves((nw + kWave - 1) / kWave), kBlock, 0, h->stream>>>(a, col, h->optimistic ? h->flags.p : nullptr)));
             }
         }
     } else {
@@ -1112,8 +1130,10 @@ int icm_sweep_finish(icm_handle* h) {
     if (h->optimistic) {   // phase A's counts and flags, read only now (the copy was queued behind k_lm_l3)
         h->E = h->pin_i[0];
         h->n_new_loc = h->pin_i[1];
-        if (h->pin_i[2] || (h->pin_i[3] & 1)) return kRetryCareful;   // a table overflowed: poses and map were left alone
-        if ((int64_t)h->lact0 + h->n_new_loc > (int64_t)L)
+        // a table overflowed (here or, sharded, on any rank: the flags travelled with the statistics): poses and map
+        // were left alone everywhere
+        if (h->pin_i[2] || (h->pin_i[3] & 1) || h->pin_i[12] || h->pin_i[13]) return ICM_RETRY_CAREFUL;
+        if (h->world == 1 && (int64_t)h->lact0 + h->n_new_loc > (int64_t)L)
             FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
     }
     // total number of landmarks created this sweep, over all ranks
@@ -1277,29 +1297,22 @@ static bool pipeline_applies(const icm_handle* h, int schedule) {
            h->hier_ok && h->gpu_filtrar && !h->x_external && pipeline_split_super(h) > 0;
 }
 
-// The sweep can be queued whole, without a host look at phase A's outcome in the middle: an unsharded red-black
-// sweep through the hierarchical pipeline, the one-launch solve and Mapa.filtrar on the device (the kernels that
-// would replace state check the sweep's flags themselves).  Not while per-kernel timing serialises the streams.
-static bool optimistic_applies(const icm_handle* h, int schedule) {
-    return schedule == ICM_SCHEDULE_REDBLACK && h->world == 1 && h->t_begin == 0 && h->form == 0 && h->fuse_colours &&
-           h->entry_path != 0 && h->hier_ok && !h->debug && !h->per_beam && !h->brute && h->gpu_filtrar && !h->timing;
-}
-
 static int icm_sweep_classic(icm_handle* h, int schedule) {
     h->pipe_used = 0;
+    const bool req = h->opt_req;
+    int rc = ICM_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        h->optimistic = attempt == 0 && optimistic_applies(h, schedule);
-        int rc = icm_sweep_local(h);
+        h->opt_req = attempt == 0 && schedule == ICM_SCHEDULE_REDBLACK;
+        rc = icm_sweep_local(h);
         if (!rc) rc = icm_sweep_targets(h);
         if (!rc) rc = icm_sweep_solve(h, schedule, -1);
         if (!rc) rc = icm_sweep_finish(h);
-        h->optimistic = false;
-        if (rc != kRetryCareful) return rc;
+        if (rc != ICM_RETRY_CAREFUL) break;
         // a per-pose or per-chunk table overflowed: solves and Mapa.filtrar saw the flags and changed nothing;
         // once more with the host looking in the middle (it sizes the tables / takes the sort-based pipeline)
-        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    return ICM_OK;
+    h->opt_req = req;
+    return rc;
 }
 
 // One red-black sweep with the two time segments software-pipelined over two streams:
@@ -1448,6 +1461,12 @@ int icm_sweep_device(icm_handle* h, int schedule) {
     return icm_sweep_classic(h, schedule);
 }
 
+int icm_set_optimistic(icm_handle* h, int on) {
+    if (!h) return ICM_ERR_ARG;
+    h->opt_req = on != 0;
+    return ICM_OK;
+}
+
 int icm_set_pipeline(icm_handle* h, int on) {
     if (!h) return ICM_ERR_ARG;
     h->pipeline = on != 0;
@@ -1533,9 +1552,25 @@ int icm_comm_destroy(icm_handle* h) {
 // One red-black sweep of a sharded sequence, the collectives issued here, on the handle's stream:
 // local phase A + statistics -> all-gather of the [3L+8] statistics -> targets -> odd poses ->
 // all-gather of the 48-byte halos -> even poses -> Mapa.filtrar (replicated).  
+static int sweep_sharded_once(icm_handle* h);
+
 int icm_sweep_sharded(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->comm) FAIL(h, ICM_ERR_ARG, "icm_sweep_sharded: no communicator (icm_comm_init)");
+    // queued whole first; if ANY rank's tables overflowed every rank sees it (the flags travel with the statistics),
+    // nothing was replaced anywhere, and every rank repeats the sweep with its host looking in the middle
+    const bool req = h->opt_req;
+    int rc = ICM_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        h->opt_req = attempt == 0;
+        rc = sweep_sharded_once(h);
+        if (rc != ICM_RETRY_CAREFUL) break;
+    }
+    h->opt_req = req;
+    return rc;
+}
+
+static int sweep_sharded_once(icm_handle* h) {
     int rc;
     if ((rc = icm_sweep_local(h))) return rc;
     const size_t stride = (size_t)icm_stats_stride(h);

@@ -999,8 +999,20 @@ __global__ __launch_bounds__(kBlock) void k_lm_scan(int nlab, int L, const int* 
 __global__ __launch_bounds__(kBlock) void k_stats_prefix(const double* __restrict__ stats_all, int stride, int rank,
                                                          int world, int L, int lact0, double* __restrict__ off_sx,
                                                          double* __restrict__ off_sy, double* __restrict__ off_n,
-                                                         double* __restrict__ y_raw, double* __restrict__ cnt_raw) {
+                                                         double* __restrict__ y_raw, double* __restrict__ cnt_raw,
+                                                         int* __restrict__ flags = nullptr) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0 && flags) {   // a sweep queued without a host look: what any rank flagged, every rank honours
+        int any = 0;
+        double total_new = 0.0;
+        for (int r = 0; r < world; ++r) {
+            const double* hd = stats_all + (size_t)r * stride + 3 * (size_t)L;
+            total_new += hd[0];
+            any |= hd[1] != 0.0;
+        }
+        if (any) flags[0] = 1;
+        if ((double)lact0 + total_new > (double)L) flags[2] = 1;   // labels beyond the map capacity, over all ranks
+    }
     if (i >= L) return;
     if (i < lact0) {
         double sx = 0.0, sy = 0.0, n = 0.0;
@@ -2208,7 +2220,9 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
 }
 
 // Red-black half sweep, moment form: one LANE per pose of the colour (64 poses per wave).
-__global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colour) {
+// abort (nullable): the sweep's flags; any of [0..2] set = leave the poses alone (a sweep queued without a host look).
+__global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colour, const int* __restrict__ abort = nullptr) {
+    if (abort && (abort[0] | abort[1] | abort[2])) return;
     const int lane = lane_id();
     constexpr int LPW = kWave;
     const int w = (blockIdx.x * kWavesPerBlock + wave_in_block()) * LPW + lane;
@@ -2333,7 +2347,8 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_deferred(SolveArgs a, SolveS
 
 // The same half sweep in latency form: one DPP quad (4 lanes) per pose, 16 poses per wave
 // (nelder_mead3_quad).  Chosen by the host when a colour has too few poses to fill the chip.
-__global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, int colour) {
+__global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, int colour, const int* __restrict__ abort = nullptr) {
+    if (abort && (abort[0] | abort[1] | abort[2])) return;
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     const int w = gid >> 2, role = gid & 3;
     int first = a.t_begin > 1 ? a.t_begin : 1;

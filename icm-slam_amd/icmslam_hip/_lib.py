@@ -16,6 +16,7 @@ ICM_ERR_INDEX = -3
 ICM_ERR_EMPTY_MAP = -4
 ICM_ERR_CAPACITY = -5
 ICM_ERR_UNSUPPORTED = -6
+RETRY_CAREFUL = 1000   # ICM_RETRY_CAREFUL (include/icmslam.h)
 SCHEDULES = {"sequential": 0, "redblack": 1}
 
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "icm_comm_destroy": (C.c_int, [_H]),
     "icm_sweep_sharded": (C.c_int, [_H]),
     "icm_gather_poses": (C.c_int, [_H]),
+    "icm_set_optimistic": (C.c_int, [_H, C.c_int]),
     "icm_sweep_local": (C.c_int, [_H]),
     "icm_sweep_targets": (C.c_int, [_H]),
     "icm_sweep_solve": (C.c_int, [_H, C.c_int, C.c_int]),

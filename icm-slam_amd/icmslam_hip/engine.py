@@ -278,7 +278,18 @@ class SweepEngine:
         self._chk(self.lib.icm_sweep_solve(self.h, SCHEDULES[schedule], int(colour)))
 
     def sweep_finish(self):
-        self._chk(self.lib.icm_sweep_finish(self.h))
+        """True = repeat the sweep's phase calls with set_optimistic(False) (a table overflowed on some rank of a sweep
+        queued without a host look; nothing was replaced)."""
+        rc = self.lib.icm_sweep_finish(self.h)
+        if rc == _lib.RETRY_CAREFUL:
+            return True
+        self._chk(rc)
+        return False
+
+    def set_optimistic(self, on=True):
+        """Phase calls only: queue the sweep without the host looking at phase A's flags in the middle
+        (icm_set_optimistic); sweep_finish then says whether the sweep has to be repeated the careful way."""
+        self._chk(self.lib.icm_set_optimistic(self.h, 1 if on else 0))
 
     def get_state(self):
         x = np.zeros((3, self.T))

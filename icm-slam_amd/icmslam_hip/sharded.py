@@ -93,20 +93,30 @@ class ShardedSweep:
     def sweep(self, schedule="redblack"):
         if schedule != "redblack":
             raise NotImplementedError("only the red-black schedule shards (the reference order is one chain)")
-        e, r = self.eng, self.rank
-        e.sweep_local()
-        self.comm.gather_stats(self)
-        e.sweep_targets()
-        if self.world == 1:        # no neighbour, no halo: both colours in the one-launch solve
-            e.sweep_solve("redblack", -1)
-            e.sweep_finish()
-            return
-        e.sweep_solve("redblack", 1)
-        self.comm.halo(self)
-        e.sweep_solve("redblack", 0)
-        if not self.native:      # (native: the even poses' boundary values ride in the next statistics message)
-            self.comm.halo(self)
-        e.sweep_finish()
+        e = self.eng
+        # Queued whole first (no host look at phase A's flags in the middle of the sweep: on the short shards of a
+        # strong-scaled job that round trip is a quarter of the sweep).  Every rank's flags travel in the header of its
+        # statistics, so if ANY rank's tables overflowed all ranks leave their state alone, all see it at the end, and
+        # all repeat the sweep the careful way.
+        can = hasattr(e, "set_optimistic") and not isinstance(self.comm, NoComm)   # (shared buffers: see run_virtual_ranks)
+        for attempt in (0, 1):
+            if can:
+                e.set_optimistic(attempt == 0)
+            e.sweep_local()
+            self.comm.gather_stats(self)
+            e.sweep_targets()
+            if self.world == 1:        # no neighbour, no halo: both colours in the one-launch solve
+                e.sweep_solve("redblack", -1)
+            else:
+                e.sweep_solve("redblack", 1)
+                self.comm.halo(self)
+                e.sweep_solve("redblack", 0)
+                if not self.native:      # (native: the even poses' boundary values ride in the next statistics message)
+                    self.comm.halo(self)
+            if not e.sweep_finish():
+                break
+        if can:
+            e.set_optimistic(False)
 
     def get_state(self):
         """(x, map, counts, K) of the whole sequence: gathers the pose blocks first."""
@@ -203,6 +213,8 @@ class NoComm:
 def run_virtual_ranks(engines, sweeps, schedule="redblack"):
     """Lock-step execution of several in-process ranks (one GPU, shared buffers): the exact
     phase order of ShardedSweep.sweep with the collectives replaced by shared memory."""
+    # (always the careful form: ranks that share buffers inside one process are ordered by the host's look at phase A
+    # in the middle of the sweep -- a sweep queued whole relies on the collective for that)
     for _ in range(sweeps):
         for e in engines:
             e.sweep_local()

@@ -32,6 +32,8 @@ extern "C" {
 #define ICM_ERR_EMPTY_MAP (-4)   /* Mapa.filtrar left no landmark (reference: ValueError)  */
 #define ICM_ERR_CAPACITY (-5)    /* a scan touched more distinct landmarks than supported  */
 #define ICM_ERR_UNSUPPORTED (-6) /* input outside what this build implements               */
+#define ICM_RETRY_CAREFUL 1000   /* icm_sweep_finish only, after icm_set_optimistic(h, 1): a table overflowed on some
+                                    rank, nothing was replaced; repeat the sweep's phase calls with icm_set_optimistic(h, 0) */
 
 #define ICM_SCHEDULE_SEQUENTIAL 0 /* reference Gauss-Seidel order (scripts/ICM_ROS.py:141) */
 #define ICM_SCHEDULE_REDBLACK 1   /* odd poses, then even poses (parallel)     */
@@ -157,6 +159,12 @@ int icm_comm_init(icm_handle *h, const void *id128, int rank, int world);
 int icm_comm_destroy(icm_handle *h);
 int icm_sweep_sharded(icm_handle *h);
 int icm_gather_poses(icm_handle *h);
+/* Phase calls only (icm_sweep_device / icm_sweep / icm_sweep_sharded do this themselves): queue the sweep whole, without
+ * the host looking at phase A's counts and overflow flags in the middle -- solves and Mapa.filtrar check the flags on
+ * the device (on every rank: the flags travel in the header of the statistics message); icm_sweep_finish then returns
+ * ICM_RETRY_CAREFUL if something overflowed.  Red-black sweeps through the default pipeline only; else the request is
+ * ignored for that sweep. */
+int icm_set_optimistic(icm_handle *h, int on);
 int icm_sweep_local(icm_handle *h);                   /* phase A + local statistics          */
 int icm_sweep_targets(icm_handle *h);                 /* prefix over ranks -> targets, map   */
 int icm_sweep_solve(icm_handle *h, int schedule, int colour); /* colour 1 = odd, 0 = even,  */

@@ -311,6 +311,53 @@ def test_scan_with_many_distinct_landmarks_grows_the_hash_table():
     assert np.abs(x - xc).max() <= 1e-9
 
 
+def test_sweep_queued_whole_recovers_from_a_table_overflow():
+    """The same overflowing case through the sweep that is queued without a host look at phase A's flags: the solves and
+    Mapa.filtrar see the overflow on the device and replace nothing, the flags come back with the sweep's one wait, and
+    the sweep is repeated the careful way -- by the library (icm_sweep_device) and by a caller of the phase calls
+    (ShardedSweep, here with a loop-back exchange at world size 1)."""
+    import torch
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import ShardedSweep
+    from oracle import c_oracle as co
+    lm, scans, x_true, u, cfgd = _dense_ring_case()
+    cfg = ConfigICM(D=cfgd)
+    odo = x_true.copy()
+    T = x_true.shape[1]
+    keptc = co.prefilter(cfg, scans)
+    xc = x_true.copy()
+    mc, cntc, Kc, _ = co.sweep(cfg, keptc, u, odo, x_true[:, 0], lm, xc, lm.shape[1], "redblack")
+
+    eng = SweepEngine(cfg)
+    eng.upload(scans, odo, u)
+    eng.set_state(lm, x_true, x_true[:, 0])
+    eng.sweep_device("redblack")
+    x, mo, cnt, K = eng.get_state()
+    eng.close()
+    assert K == Kc and np.array_equal(cnt, cntc) and np.abs(mo[:, :K] - mc).max() <= 1e-9 and np.abs(x - xc).max() <= 1e-9
+
+    class Loopback:   # world size 1: the rank's own statistics are the gathered ones
+        def gather_stats(self, sw):
+            sw.stats[:sw.stride].copy_(sw.stats_send)
+
+        def halo(self, sw):
+            raise AssertionError("no halo at world size 1")
+
+        def all_gather(self, buf, rank, count):
+            pass
+
+    eng = SweepEngine(cfg)
+    eng.upload(scans, odo, u)
+    run = ShardedSweep(eng, 0, 1, T, comm=Loopback())
+    run.set_state(lm, x_true, x_true[:, 0])
+    run.sweep("redblack")
+    torch.cuda.synchronize()
+    x2, m2, c2, K2 = run.get_state()
+    eng.close()
+    assert K2 == K and np.array_equal(x2, x) and np.array_equal(m2, mo) and np.array_equal(c2, cnt)
+
+
 def test_handle_reuse_with_longer_sequence():
     """One handle, a short sequence then a longer one (ICM_ROS re-uploads when its data change)."""
     from icmslam_hip import SweepEngine
