@@ -655,7 +655,10 @@ struct PoseTable {
     double sy[HS];
 };
 
-template <bool PRELABEL, bool DEBUG, int HS>
+// PPW consecutive poses per wave (1 or more; > 1 only for the plain configuration, with the rotation table): while a
+// pose is grouped, the next pose's header (beam range, pose, rotation -- scalar loads) and its first 64 beams are
+// already in flight, so only the wave's first pose pays the dependent chain beam offsets -> beams -> grid record.
+template <bool PRELABEL, bool DEBUG, int HS, int PPW = 1>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_ASSOC_WPE : 4, HS == 128 ? 8 : 5)))
 void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int t_begin, int nloc, const int* __restrict__ boff,
@@ -665,23 +668,61 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int* __restrict__ st_k, double* __restrict__ st_sbx,
                                                         double* __restrict__ st_sby, int* __restrict__ nent_out,
                                                         int* __restrict__ isnew_out, int* __restrict__ flags,
-                                                        const double* __restrict__ rot = nullptr) {
+                                                        const double* __restrict__ rot = nullptr, int nnz_total = 0) {
+    static_assert(PPW == 1 || (!PRELABEL && !DEBUG), "several poses per wave: plain configuration only");
     constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
     constexpr int kHashShift = HS == 128 ? 25 : 24;
     __shared__ PoseTable<HS> tables[kWavesPerBlock];
     const int lane = lane_id();
-    const int tl = blockIdx.x * kWavesPerBlock + wave_in_block();
-    if (tl >= nloc) return;
+    const int w0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + wave_in_block()) * PPW);
+    if (w0 >= nloc) return;
     PoseTable<HS>& T = tables[wave_in_block()];
+    const GridParams gp = *g.par;
+    // (explicit 32-bit byte offsets from a scalar base: a pose has far fewer than 2^29 beams)
+    auto beam_at = [](const double* __restrict__ base, unsigned idx) {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
+    };
+    // header and first 64 beams of the pose that comes next (at first: of the wave's first pose)
+    int hj0 = __builtin_amdgcn_readfirstlane(boff[w0]), hj1 = __builtin_amdgcn_readfirstlane(boff[w0 + 1]);
+    double hpx, hpy, hth, hct, hst;
+    pose_of(x, x0, t_begin + w0, hpx, hpy, hth);
+    if (rot) {   // (cos, sin)(theta - pi/2) from the sweep's table: the same values, computed once
+        hct = rot[2 * (size_t)w0];
+        hst = rot[2 * (size_t)w0 + 1];
+    } else {
+        pose_rot(hth, hct, hst);
+    }
+    double fbx = 0.0, fby = 0.0;
+    if (hj1 > hj0) {
+        const unsigned i0 = min((unsigned)lane, (unsigned)(hj1 - hj0) - 1u);
+        fbx = beam_at(bx + hj0, i0);
+        fby = beam_at(by + hj0, i0);
+    }
+#pragma unroll 1
+    for (int pp = 0; pp < PPW; ++pp) {
+    const int tl = w0 + pp;
+    if (tl >= nloc) break;
     // (wave-uniform values through scalar registers: the pose's beam range becomes a scalar base pointer plus a
     // 32-bit lane offset)
-    const int j0 = __builtin_amdgcn_readfirstlane(boff[tl]), j1 = __builtin_amdgcn_readfirstlane(boff[tl + 1]);
+    const int j0 = hj0, j1 = hj1;
+    const double px = hpx, py = hpy, ct = hct, st = hst;
+    double nbx = fbx, nby = fby;
+    if (PPW > 1 && pp + 1 < PPW && tl + 1 < nloc) {   // the next pose's header and first beams, requested now
+        hj0 = j1;
+        hj1 = __builtin_amdgcn_readfirstlane(boff[tl + 2]);
+        pose_of(x, x0, t_begin + tl + 1, hpx, hpy, hth);
+        hct = rot[2 * (size_t)(tl + 1)];
+        hst = rot[2 * (size_t)(tl + 1) + 1];
+        const unsigned i1 = min((unsigned)lane, (unsigned)(nnz_total - j1) - 1u);   // (clamped to the shard's last beam)
+        fbx = beam_at(bx + j1, i1);
+        fby = beam_at(by + j1, i1);
+    }
     if (j0 == j1) {
         if (lane == 0) {
             nent_out[tl] = 0;
             isnew_out[tl] = 0;
         }
-        return;
+        continue;
     }
     const double* __restrict__ bxp = bx + j0;
     const double* __restrict__ byp = by + j0;
@@ -692,27 +733,12 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         T.sx[s] = 0.0;
         T.sy[s] = 0.0;
     }
-    double px, py, th;
-    pose_of(x, x0, t_begin + tl, px, py, th);
-    double ct, st;
-    if (rot) {   // (cos, sin)(theta - pi/2) from the sweep's table (k_pose_rot): the same values, computed once
-        ct = rot[2 * (size_t)tl];
-        st = rot[2 * (size_t)tl + 1];
-    } else {
-        pose_rot(th, ct, st);
-    }
-    const GridParams gp = *g.par;
     int nent = 0;
     bool overflow = false;
     __builtin_amdgcn_wave_barrier();
     // body points of the next 64 beams are requested one iteration ahead (unconditional loads at a clamped
     // index, so that the wait in front of their use counts exactly them): a pose's batches no longer pay the
     // latency of this load and of the grid record's one after the other
-    // (explicit 32-bit byte offsets: a pose has far fewer than 2^29 beams)
-    auto beam_at = [](const double* __restrict__ base, unsigned idx) {
-        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
-    };
-    double nbx = beam_at(bxp, min((unsigned)lane, nbeam - 1u)), nby = beam_at(byp, min((unsigned)lane, nbeam - 1u));
     for (int base = j0; base < j1 && !overflow; base += kWave) {
         const int j = base + lane;
         const bool valid = j < j1;
@@ -842,6 +868,8 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         __threadfence_block();
         for (int j = j0 + lane; j < j1; j += kWave) bloc[j] = T.owner[bloc[j]];
     }
+    __builtin_amdgcn_wave_barrier();   // (the table is cleared for the wave's next pose)
+    }   // poses of this wave
 }
 
 // Running-mean term of one entry: sum of its beams' world points and their count.  One
