@@ -2310,7 +2310,7 @@ __device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, const Solve
     }
 }
 
-#ifdef ICM_WAVE_TS   // measurement builds only (scratch/wave_timeline.py): per-wave start / go / end times
+#ifdef ICM_WAVE_TS   // measurement builds only (tools/wave_timeline.py): per-wave start / go / end times
 __device__ unsigned long long g_wave_ts[4 * 16384];
 #define WAVE_TS(slot) do { if (lane == 0 && gw < 16384) g_wave_ts[4 * gw + (slot)] = wall_clock64(); } while (0)
 #else

@@ -1,6 +1,6 @@
 """Back-to-back dependence statistics of a kernel's VALU stream (gfx950 .s from --save-temps).
 A lone wavefront issues a VALU instruction that depends on the one right before it every ~8.4 cycles and an
-independent one every ~5.5 cycles (scratch/ubench_issue.hip), so the share of dependent neighbours in a
+independent one every ~5.5 cycles (tools/ubench_issue.hip), so the share of dependent neighbours in a
 latency-bound kernel's hot loop is its headroom from instruction scheduling alone.
 usage: isa_dep_chain.py file.s kernel-substring [first_line last_line]"""
 import re
