@@ -112,6 +112,8 @@ struct icm_handle {
     DevBuf<int> rec_label;
     DevBuf<double> rec_s, rec_off, ms;   // [3][nrec], [3][nrec], [3][nsuper][L]
     int nchunks = 0, chunk_poses = 64, chunk_group = 1, nsuper = 0;
+    DevBuf<int> st_off;      // where each pose's staged entries start (k_assoc_group: packed area or sparse area)
+    int64_t st_sparse0 = 0;  // first entry of the sparse area (behind the packed one)
     // icm_snapshot_state / icm_restore_state: device copy of the sweep state (poses, map, search structures)
     struct Snapshot {
         DevBuf<double> x, mapx, mapy, counts_new;
@@ -374,7 +376,7 @@ int icm_destroy(icm_handle* h) {
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->solve_stream) { (void)hipStreamSynchronize(h->solve_stream); (void)hipStreamDestroy(h->solve_stream); }
     for (int q = 0; q < 2; ++q) { if (h->ev_m[q]) (void)hipEventDestroy(h->ev_m[q]); if (h->ev_s[q]) (void)hipEventDestroy(h->ev_s[q]); }
-    h->x_bak.release(); h->l3_carry.release(); h->scan_carry.release(); h->rot.release();
+    h->x_bak.release(); h->l3_carry.release(); h->scan_carry.release(); h->rot.release(); h->st_off.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ICM_OK;
@@ -497,8 +499,13 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->rot.reserve(2 * (size_t)nloc));
     TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p)));
     // per-sweep buffers sized by the kept beams
-    HIPCHK(h, h->label.reserve(nz)); HIPCHK(h, h->bloc.reserve(nz)); HIPCHK(h, h->st_label.reserve(nz));
-    HIPCHK(h, h->st_k.reserve(nz)); HIPCHK(h, h->st_sx.reserve(nz)); HIPCHK(h, h->st_sy.reserve(nz));
+    // staged entries: the packed area (last sweep's entry count of every pose + kStageSlack) and, behind it, the sparse one
+    h->st_sparse0 = (int64_t)nz + (int64_t)kStageSlack * nloc + kWave;
+    if (h->st_sparse0 + (int64_t)nz + 512 > (int64_t)0x7fffffff) FAIL(h, ICM_ERR_CAPACITY, "too many kept beams for 32-bit entry offsets");
+    const size_t nst = (size_t)h->st_sparse0 + nz + 512;
+    HIPCHK(h, h->label.reserve(nz)); HIPCHK(h, h->bloc.reserve(nz)); HIPCHK(h, h->st_label.reserve(nst));
+    HIPCHK(h, h->st_k.reserve(nst)); HIPCHK(h, h->st_sx.reserve(nst)); HIPCHK(h, h->st_sy.reserve(nst));
+    HIPCHK(h, h->st_off.reserve((size_t)nloc + 1));
     HIPCHK(h, h->btx.reserve(nz)); HIPCHK(h, h->bty.reserve(nz));
     HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz + kWave));
     HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_b.reserve(nz));
@@ -506,6 +513,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->scan_tot.reserve(2 * ((size_t)nloc / kScanTile + 2)));
     HIPCHK(h, h->nent.reserve((size_t)nloc + 1)); HIPCHK(h, h->isnew.reserve((size_t)nloc + 1));
     HIPCHK(h, h->ent_off.reserve((size_t)nloc + 1)); HIPCHK(h, h->new_rank.reserve((size_t)nloc + 1));
+    HIPCHK(h, hipMemsetAsync(h->ent_off.p, 0, ((size_t)nloc + 1) * sizeof(int), h->stream));   // (no reservation plan yet: k_assoc_group)
     const size_t L = (size_t)h->cfg.L;
     HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(8));
     HIPCHK(h, h->stats_own.reserve(3 * L + 8)); HIPCHK(h, h->off_sx.reserve(L)); HIPCHK(h, h->off_sy.reserve(L));
@@ -839,7 +847,7 @@ int icm_sweep_local(icm_handle* h) {
     TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS, (PRE || DBG) ? 1 : ICM_ASSOC_PPW>                         \
         <<<nblocks_waves((nloc + ((PRE || DBG) ? 1 : ICM_ASSOC_PPW) - 1) / ((PRE || DBG) ? 1 : ICM_ASSOC_PPW)), kBlock, 0, h->stream>>>( \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
-        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p, (int)h->nnz)))
+        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->st_sparse0)))
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
     if (!h->rot_valid) {   // (the poses came from the host, a snapshot or a solve form that does not keep the table)
         TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p)));
@@ -868,7 +876,7 @@ int icm_sweep_local(icm_handle* h) {
         if (hier) {  // launched before the host looks at the counts: one synchronisation per sweep
 #define CHUNK_L1(CH)                                                                                                   \
     TIMED(h, KID_CHUNK_L1, (k_chunk_l1<CH><<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(                          \
-        h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->boff.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0,   \
+        h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->st_off.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0, \
         h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, reinterpret_cast<unsigned*>(pre + 2 * nzs),        \
         reinterpret_cast<unsigned char*>(h->e_val.p),                                                                   \
         h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave)))
@@ -925,7 +933,7 @@ int icm_sweep_local(icm_handle* h) {
         HIPCHK(h, hipGetLastError());
         return ICM_OK;
     }
-    TIMED(h, KID_COMPACT, (k_compact<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, h->e_key.p, h->e_val.p, h->e_k.p, h->form == 2 ? h->e_b.p : nullptr, h->e_w.p, h->e_wr.p, h->pose_c.p)));
+    TIMED(h, KID_COMPACT, (k_compact<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->st_off.p, h->ent_off.p, h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, h->e_key.p, h->e_val.p, h->e_k.p, h->form == 2 ? h->e_b.p : nullptr, h->e_w.p, h->e_wr.p, h->pose_c.p)));
     int bits = 1;
     while ((1ll << bits) < (int64_t)nlab + 1) ++bits;
     size_t tmp_bytes = h->sort_tmp.cap;
@@ -970,7 +978,7 @@ int icm_sweep_targets(icm_handle* h) {
             h->world > 1 ? h->off_sx.p : nullptr, h->world > 1 ? h->off_sy.p : nullptr, h->world > 1 ? h->off_n.p : nullptr,
             ro, ro + nrec, ro + 2 * (size_t)nrec)));
         TIMED(h, KID_POSE_MOMENTS, (k_pose_moments_h<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(
-            h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p,
+            h->x, h->x0.p, (int)h->t_begin, nloc, h->st_off.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p,
             pre, pre + nzs, reinterpret_cast<const unsigned*>(pre + 2 * nzs), reinterpret_cast<const unsigned char*>(h->e_val.p), h->chunk_poses,
             ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr, 0, -1, h->rot.p)));
     } else if (h->world > 1) {
@@ -1376,7 +1384,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
 #define ASSOC_SEG(HS)                                                                                                 \
     k_assoc_group<false, false, HS><<<nbw, kBlock, 0, X>>>(h->x, h->x0.p, t0, nseg, h->boff.p + t0, h->bx.p, h->by.p, gv,  \
         h->cfg.dist_thr, h->thr2, h->label.p, h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p + t0, \
-        h->isnew.p + t0, h->flags.p, h->rot.p + 2 * (size_t)t0)
+        h->isnew.p + t0, h->flags.p, h->rot.p + 2 * (size_t)t0, (int)h->nnz, h->st_off.p + t0, h->ent_off.p + t0, t0, (int)h->st_sparse0)
         if (h->hash_slots == 128) ASSOC_SEG(128); else ASSOC_SEG(256);
 #undef ASSOC_SEG
         const int ntiles = (nseg + kScanTile - 1) / kScanTile;
@@ -1384,7 +1392,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
         k_scan_fix<<<ntiles, kBlock, 0, X>>>(h->ent_off.p + t0, h->new_rank.p + t0, h->scan_tot.p, nseg, ntiles,
                                              seg ? h->scan_carry.p : nullptr, seg ? nullptr : h->scan_carry.p);
 #define CHUNK_L1(CHV)                                                                                                  \
-    k_chunk_l1<CHV><<<nblocks_waves(c1 - c0), kBlock, 0, X>>>(h->x, h->x0.p, 0, nloc, c1, h->boff.p, h->nent.p, h->ent_off.p, \
+    k_chunk_l1<CHV><<<nblocks_waves(c1 - c0), kBlock, 0, X>>>(h->x, h->x0.p, 0, nloc, c1, h->st_off.p, h->nent.p, h->ent_off.p, \
         h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs,                          \
         reinterpret_cast<unsigned*>(pre + 2 * nzs), reinterpret_cast<unsigned char*>(h->e_val.p), h->rec_label.p, h->rec_s.p, \
         h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave, c0)
@@ -1399,7 +1407,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
         k_rec_push<<<nblocks_threads((int64_t)(c1 - c0) * kT1), kBlock, 0, X>>>(c1 * kT1, G, L, h->rec_label.p, ms, ms + msn, ms + 2 * msn,
                                                                                nullptr, nullptr, nullptr, ro, ro + nrec, ro + 2 * (size_t)nrec, c0 * kT1);
         k_pose_moments_h<<<nblocks_threads((int64_t)nseg * 16), kBlock, 0, X>>>(
-            h->x, h->x0.p, 0, nloc, h->boff.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, pre, pre + nzs,
+            h->x, h->x0.p, 0, nloc, h->st_off.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, pre, pre + nzs,
             reinterpret_cast<const unsigned*>(pre + 2 * nzs), reinterpret_cast<const unsigned char*>(h->e_val.p), CH, ro, ro + nrec,
             ro + 2 * (size_t)nrec, h->pose_m.p, nullptr, t0, t1, h->rot.p);
         HIPCHK(h, hipGetLastError());

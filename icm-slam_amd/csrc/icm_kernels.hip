@@ -639,6 +639,16 @@ __device__ __forceinline__ void seg_step_rows(bool take, double& ax, double& ay)
     }
 }
 
+// Where a pose's staged entries go.  Dense, without a scan in front and without an atomic: the PREVIOUS sweep's
+// exclusive scan of the entry counts (still in ent_off when phase A runs) is this sweep's reservation plan -- pose t owns
+// [E_prev[t] + kStageSlack t, E_prev[t+1] + kStageSlack (t+1)) of the packed area, room for its last count plus a slack.
+// The plan is disjoint whatever the array holds (stale after a restore, zero before the first sweep: any non-decreasing
+// array works), so a pose whose entries fit takes its reserved place and one whose do not takes the front of its own beam
+// range in the sparse area behind the packed one -- always correct, dense once the counts have settled (on S2 every pose
+// from the second sweep on).  The readers stream a pose's ~37 entries from consecutive memory instead of from the front of
+// every 230-beam range.
+constexpr int kStageSlack = 4;
+
 // HS = hash slots per pose; at most 3/4 of them may be used (distinct landmarks of one scan).
 // HS = 128 keeps the kernel at 14 KB of LDS and 64 VGPRs = 8 waves per SIMD (the kernel waits
 // on memory 2/3 of the time, so occupancy matters); a scan that overflows it makes the host
@@ -668,7 +678,9 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int* __restrict__ st_k, double* __restrict__ st_sbx,
                                                         double* __restrict__ st_sby, int* __restrict__ nent_out,
                                                         int* __restrict__ isnew_out, int* __restrict__ flags,
-                                                        const double* __restrict__ rot = nullptr, int nnz_total = 0) {
+                                                        const double* __restrict__ rot = nullptr, int nnz_total = 0,
+                                                        int* __restrict__ st_off = nullptr, const int* __restrict__ plan = nullptr,
+                                                        int pose0 = 0, int sparse0 = 0) {
     static_assert(PPW == 1 || (!PRELABEL && !DEBUG), "several poses per wave: plain configuration only");
     constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
     constexpr int kHashShift = HS == 128 ? 25 : 24;
@@ -721,9 +733,12 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         if (lane == 0) {
             nent_out[tl] = 0;
             isnew_out[tl] = 0;
+            st_off[tl] = 0;
         }
         continue;
     }
+    // this pose's reserved place (scalar loads, in flight while the beams are grouped)
+    const int plan0 = __builtin_amdgcn_readfirstlane(plan[tl]), plan1 = __builtin_amdgcn_readfirstlane(plan[tl + 1]);
     const double* __restrict__ bxp = bx + j0;
     const double* __restrict__ byp = by + j0;
     const unsigned nbeam = (unsigned)(j1 - j0);
@@ -838,7 +853,11 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         if (nent > kGroupCap) overflow = true;
         __builtin_amdgcn_wave_barrier();
     }
-    // compact the used slots into the staging area, slot order
+    // compact the used slots into the pose's place, slot order: its reserved one if the entries fit, else the front
+    // of its own beam range in the sparse area
+    const int room = (plan1 - plan0) + kStageSlack;
+    const bool fits = plan0 >= 0 && plan1 >= plan0 && plan1 <= nnz_total && nent <= room;   // (a stale plan is still a plan; a wild one is not)
+    const int sbase = fits ? plan0 + kStageSlack * (pose0 + tl) : sparse0 + j0;
     int written = 0;
     bool isnew = false;
     for (int s0 = 0; s0 < kHash; s0 += kWave) {
@@ -848,10 +867,10 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         const unsigned long long mask = __ballot(occ);
         if (occ) {
             const unsigned q = (unsigned)(written + prefix_count(mask, lane));   // (scalar bases + 32-bit offsets, like the beam loads)
-            *reinterpret_cast<int*>(reinterpret_cast<char*>(st_label + j0) + (q << 2)) = k;
-            *reinterpret_cast<int*>(reinterpret_cast<char*>(st_k + j0) + (q << 2)) = T.cnt[s];
-            *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sbx + j0) + (q << 3)) = T.sx[s];
-            *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sby + j0) + (q << 3)) = T.sy[s];
+            *reinterpret_cast<int*>(reinterpret_cast<char*>(st_label + sbase) + (q << 2)) = k;
+            *reinterpret_cast<int*>(reinterpret_cast<char*>(st_k + sbase) + (q << 2)) = T.cnt[s];
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sbx + sbase) + (q << 3)) = T.sx[s];
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sby + sbase) + (q << 3)) = T.sy[s];
             isnew |= k == -1;
             if (DEBUG) T.owner[s] = q;
         }
@@ -860,6 +879,7 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     const unsigned long long anynew = __ballot(isnew);
     if (lane == 0) {
         nent_out[tl] = written;
+        st_off[tl] = sbase;
         isnew_out[tl] = anynew != 0ull;
         if (overflow) flags[0] = 1;
     }
