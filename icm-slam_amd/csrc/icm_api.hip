@@ -114,6 +114,7 @@ struct icm_handle {
     int nchunks = 0, chunk_poses = 64, chunk_group = 1, nsuper = 0;
     DevBuf<int> st_off;      // where each pose's staged entries start (k_assoc_group: packed area or sparse area)
     int64_t st_sparse0 = 0;  // first entry of the sparse area (behind the packed one)
+    size_t st_stride = 0;    // entries of the staging area (+ the dump row): stride of the per-entry prefix arrays
     // icm_snapshot_state / icm_restore_state: device copy of the sweep state (poses, map, search structures)
     struct Snapshot {
         DevBuf<double> x, mapx, mapy, counts_new;
@@ -506,10 +507,13 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->label.reserve(nz)); HIPCHK(h, h->bloc.reserve(nz)); HIPCHK(h, h->st_label.reserve(nst));
     HIPCHK(h, h->st_k.reserve(nst)); HIPCHK(h, h->st_sx.reserve(nst)); HIPCHK(h, h->st_sy.reserve(nst));
     HIPCHK(h, h->st_off.reserve((size_t)nloc + 1));
+    h->st_stride = nst + kWave;
     HIPCHK(h, h->btx.reserve(nz)); HIPCHK(h, h->bty.reserve(nz));
-    HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz + kWave));
+    HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(std::max<size_t>(nz + kWave, (h->st_stride + 3) / 4 + kWave)));
     HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_b.reserve(nz));
-    HIPCHK(h, h->e_w.reserve(nz + kWave)); HIPCHK(h, h->e_wr.reserve(nz)); HIPCHK(h, h->tgt.reserve(nz));
+    // (e_w also holds the three per-entry prefix arrays of the hierarchical path, e_val its record ids: one per staging place)
+    HIPCHK(h, h->e_w.reserve(std::max<size_t>(nz + kWave, (3 * h->st_stride * sizeof(double) + sizeof(EntW) - 1) / sizeof(EntW) + kWave)));
+    HIPCHK(h, h->e_wr.reserve(nz)); HIPCHK(h, h->tgt.reserve(nz));
     HIPCHK(h, h->scan_tot.reserve(2 * ((size_t)nloc / kScanTile + 2)));
     HIPCHK(h, h->nent.reserve((size_t)nloc + 1)); HIPCHK(h, h->isnew.reserve((size_t)nloc + 1));
     HIPCHK(h, h->ent_off.reserve((size_t)nloc + 1)); HIPCHK(h, h->new_rank.reserve((size_t)nloc + 1));
@@ -862,7 +866,7 @@ int icm_sweep_local(icm_handle* h) {
     bool hier = h->entry_path != 0 && h->hier_ok && h->form == 0 && (!dbg || h->entry_path == 1);
     const int nrec = h->nchunks * kT1;
     double* const pre = reinterpret_cast<double*>(h->e_w.p);   // [3][nnz] (the sort-based path's record buffer)
-    const size_t nzs = (size_t)std::max<int64_t>(h->nnz, 1) + kWave;   // + the dump row of k_chunk_l1
+    const size_t nzs = h->st_stride;   // + the dump row of k_chunk_l1
     double* const ms = h->ms.p;
     const size_t msn = (size_t)h->nsuper * (size_t)L;
     for (;;) {
@@ -968,7 +972,7 @@ int icm_sweep_targets(icm_handle* h) {
     if (h->path_used == 1) {
         const int nrec = h->nchunks * kT1;
         const size_t msn = (size_t)h->nsuper * (size_t)L;
-        const size_t nzs = (size_t)std::max<int64_t>(h->nnz, 1) + kWave;
+        const size_t nzs = h->st_stride;
         const double* pre = reinterpret_cast<const double*>(h->e_w.p);
         double* ro = h->rec_off.p;
         if (h->world > 1)
@@ -1345,7 +1349,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
     const int s_split = pipeline_split_super(h), c_split = s_split * G, M = c_split * CH;
     const int nrec = NC * kT1;
     double* const pre = reinterpret_cast<double*>(h->e_w.p);
-    const size_t nzs = (size_t)std::max<int64_t>(h->nnz, 1) + kWave;
+    const size_t nzs = h->st_stride;
     double* const ms = h->ms.p;
     const size_t msn = (size_t)S * (size_t)L;
     double* const ro = h->rec_off.p;

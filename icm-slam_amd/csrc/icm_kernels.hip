@@ -1219,9 +1219,9 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
     int j0 = 0, n = 0, e0 = 0, nr = 0;
     double px = 0.0, py = 0.0, th = 0.0;
     if (lane < kCH && tl < nloc) {
-        j0 = boff[tl];
+        j0 = boff[tl];      // (the pose's place in the staging area: st_off)
         n = nent[tl];
-        e0 = ent_off[tl];
+        e0 = j0;            // the per-entry prefixes live at the entries' own places: no entry-offset scan needed for them
         nr = new_rank[tl];
         pose_of(x, x0, t_begin + tl, px, py, th);
     }
@@ -2161,10 +2161,11 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
     int j0 = 0, e0 = 0, n = 0;
     if (live) {
         pose_of(x, x0, t_begin + tl, px, py, th);
-        j0 = boff[tl];
-        e0 = ent_off[tl];
+        j0 = boff[tl];      // (the pose's place in the staging area: st_off; the per-entry prefixes are at the same places)
+        e0 = j0;
         n = nent[tl];
     }
+    const int et = (live && tgt_out) ? ent_off[tl] : 0;   // the association dump keeps the scan's (pose-major, gap-free) numbering
     double ct, st;
     if (rot) {
         ct = live ? rot[2 * (size_t)tl] : 1.0;
@@ -2181,7 +2182,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
         const int r = (tl / chunk_poses) * kT1 + (int)e_rec[e0 + q];
         const double sx = off_x[r] + pre_x[e0 + q], sy = off_y[r] + pre_y[e0 + q], sn = off_n[r] + (double)pre_n[e0 + q];
         const double tx = sx / sn, ty = sy / sn;
-        if (tgt_out) tgt_out[e0 + q] = make_double2(tx, ty);   // association dump (icm_set_debug)
+        if (tgt_out) tgt_out[et + q] = make_double2(tx, ty);   // association dump (icm_set_debug)
         const double wx = (ct * sbx - st * sby) / k, wy = (st * sbx + ct * sby) / k;
         const double rx = (px + wx) - tx, ry = (py + wy) - ty;
         m[0] += k; m[1] += k * wx; m[2] += k * wy; m[3] += k * rx; m[4] += k * ry;
