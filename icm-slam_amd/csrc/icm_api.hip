@@ -179,6 +179,10 @@ struct icm_handle {
     // and overflow flags in the middle; the kernels that would replace state (solves, Mapa.filtrar) look at the
     // flags themselves, the host reads them with the filtrar result and repeats the sweep the careful way if set.
     bool optimistic = false;   // this sweep is queued whole (decided at its start, icm_sweep_local)
+    DevBuf<unsigned long long> chunk_pub;   // k_chunk_l1 without the scan kernels: new-landmark count of every chunk, epoch-tagged
+    unsigned scan_epoch = 0;
+    bool scan_wanted = true;   // the next queued-whole sweep runs the scan kernels (new-landmark ranks, a fresh reservation plan)
+    bool scan_ran = true;      // ... this sweep did
     bool opt_req = false;      // asked for: by icm_sweep_classic for its first attempt, by icm_set_optimistic for the phase calls
     int pipe_used = 0;               // the last sweep ran pipelined
     DevBuf<double> x_bak, l3_carry;
@@ -377,7 +381,7 @@ int icm_destroy(icm_handle* h) {
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->solve_stream) { (void)hipStreamSynchronize(h->solve_stream); (void)hipStreamDestroy(h->solve_stream); }
     for (int q = 0; q < 2; ++q) { if (h->ev_m[q]) (void)hipEventDestroy(h->ev_m[q]); if (h->ev_s[q]) (void)hipEventDestroy(h->ev_s[q]); }
-    h->x_bak.release(); h->l3_carry.release(); h->scan_carry.release(); h->rot.release(); h->st_off.release();
+    h->x_bak.release(); h->l3_carry.release(); h->scan_carry.release(); h->rot.release(); h->st_off.release(); h->chunk_pub.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ICM_OK;
@@ -519,7 +523,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->ent_off.reserve((size_t)nloc + 1)); HIPCHK(h, h->new_rank.reserve((size_t)nloc + 1));
     HIPCHK(h, hipMemsetAsync(h->ent_off.p, 0, ((size_t)nloc + 1) * sizeof(int), h->stream));   // (no reservation plan yet: k_assoc_group)
     const size_t L = (size_t)h->cfg.L;
-    HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(8));
+    HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(16));   // [0..7] the sweep's flags and host words, [8..9] totals of a sweep without scan kernels
     HIPCHK(h, h->stats_own.reserve(3 * L + 8)); HIPCHK(h, h->off_sx.reserve(L)); HIPCHK(h, h->off_sy.reserve(L));
     HIPCHK(h, h->off_n.reserve(L));
     {
@@ -534,6 +538,14 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     {
         const size_t nrec = (size_t)h->nchunks * kT1;
         HIPCHK(h, h->rec_label.reserve(nrec)); HIPCHK(h, h->rec_s.reserve(3 * nrec)); HIPCHK(h, h->rec_off.reserve(3 * nrec));
+        {
+            const size_t had = h->chunk_pub.cap;
+            HIPCHK(h, h->chunk_pub.reserve((size_t)h->nchunks + 1));
+            if (h->chunk_pub.cap != had) {   // fresh storage: its tags must not match any epoch
+                HIPCHK(h, hipMemsetAsync(h->chunk_pub.p, 0, h->chunk_pub.cap * sizeof(unsigned long long), h->stream));
+                h->scan_epoch = 0;
+            }
+        }
         HIPCHK(h, h->ms.reserve(3 * (size_t)h->nsuper * L));
         h->ms_clean = false;
     }
@@ -630,6 +642,7 @@ static int set_state_impl(icm_handle* h, const double* x, const double* x0, cons
     }
     h->have_state = true;
     h->rot_valid = false;
+    h->scan_wanted = true;
     h->hier_ok = true;
     h->pipe_ok = true;
     if (wait_host) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -750,7 +763,9 @@ static FiltrarArgs filtrar_args(icm_handle* h) {
     const int L = (int)h->cfg.L;
     FiltrarArgs fa;
     fa.y_raw = h->y_raw.p; fa.cnt_raw = h->cnt_raw.p; fa.stats_all = h->world > 1 ? h->stats_all : nullptr;
-    fa.n_new_dev = h->new_rank.p + h->nloc;   // (total of the new-landmark scan, single rank)
+    // landmarks created this sweep (single rank): the total of the new-landmark scan, or, in a sweep without the scan
+    // kernels, the count k_chunk_l1 added up
+    fa.n_new_dev = h->scan_ran ? h->new_rank.p + h->nloc : h->flags.p + 9;
     fa.sweep_flags = nullptr;
     fa.L = L; fa.lact0 = h->lact0; fa.world = h->world; fa.stride = (int)icm_stats_stride(h);
     fa.cota = h->cfg.cota; fa.thr = h->cfg.dist_thr; fa.max_cells = h->max_cells;
@@ -840,7 +855,7 @@ int icm_sweep_local(icm_handle* h) {
     h->lact0 = (int)h->lact;
     const int km = (int)std::min(h->K, h->lact);
     const int nbw = nblocks_waves(nloc);
-    HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 16 * sizeof(int), h->stream));
     GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p};
     const bool dbg = h->debug || h->per_beam;
     h->assoc_kept = dbg;
@@ -851,7 +866,7 @@ int icm_sweep_local(icm_handle* h) {
     TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS, (PRE || DBG) ? 1 : ICM_ASSOC_PPW>                         \
         <<<nblocks_waves((nloc + ((PRE || DBG) ? 1 : ICM_ASSOC_PPW) - 1) / ((PRE || DBG) ? 1 : ICM_ASSOC_PPW)), kBlock, 0, h->stream>>>( \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
-        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->st_sparse0)))
+        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->st_sparse0, run_scan ? 0 : 1)))
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
     if (!h->rot_valid) {   // (the poses came from the host, a snapshot or a solve form that does not keep the table)
         TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p)));
@@ -864,6 +879,12 @@ int icm_sweep_local(icm_handle* h) {
     // sort-based pipeline when the per-beam / per-entry cross-check forms or the association
     // dump need its per-entry arrays, when asked for, or after a table overflow.
     bool hier = h->entry_path != 0 && h->hier_ok && h->form == 0 && (!dbg || h->entry_path == 1);
+    // The scan kernels lay next sweep's reservation plan (and rank the new landmarks for the sort-based pipeline); the
+    // hierarchical kernels no longer need them: their per-entry arrays live at the staging places, and the few poses that
+    // create a landmark get their ranks inside k_chunk_l1.  A sweep queued whole leaves the scan out while nearly every
+    // pose fitted its reserved place last time.
+    const bool run_scan = !(h->optimistic && hier) || h->scan_wanted;
+    h->scan_ran = run_scan;
     const int nrec = h->nchunks * kT1;
     double* const pre = reinterpret_cast<double*>(h->e_w.p);   // [3][nnz] (the sort-based path's record buffer)
     const size_t nzs = h->st_stride;   // + the dump row of k_chunk_l1
@@ -875,15 +896,19 @@ int icm_sweep_local(icm_handle* h) {
         } else {
             if (dbg) ASSOC_GROUP_HS(false, true); else ASSOC_GROUP_HS(false, false);
         }
-        TIMED(h, KID_SCAN, (k_scan_tiles<<<ntiles, kBlock, 0, h->stream>>>(h->nent.p, h->isnew.p, h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc)));
-        TIMED(h, KID_SCAN, (k_scan_fix<<<ntiles, kBlock, 0, h->stream>>>(h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc, ntiles)));
+        if (!run_scan && ++h->scan_epoch == 0u) ++h->scan_epoch;   // (tag 0 = never written)
+        if (run_scan) {
+            TIMED(h, KID_SCAN, (k_scan_tiles<<<ntiles, kBlock, 0, h->stream>>>(h->nent.p, h->isnew.p, h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc)));
+            TIMED(h, KID_SCAN, (k_scan_fix<<<ntiles, kBlock, 0, h->stream>>>(h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc, ntiles)));
+        }
         if (hier) {  // launched before the host looks at the counts: one synchronisation per sweep
 #define CHUNK_L1(CH)                                                                                                   \
     TIMED(h, KID_CHUNK_L1, (k_chunk_l1<CH><<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(                          \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->st_off.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0, \
         h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, reinterpret_cast<unsigned*>(pre + 2 * nzs),        \
         reinterpret_cast<unsigned char*>(h->e_val.p),                                                                   \
-        h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave)))
+        h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave, 0,          \
+        run_scan ? nullptr : h->flags.p + 8, h->isnew.p, h->chunk_pub.p, h->scan_epoch, 1 << 16)))
             if (h->chunk_poses == 64) CHUNK_L1(64); else if (h->chunk_poses == 32) CHUNK_L1(32); else CHUNK_L1(16);
 #undef CHUNK_L1
             if (!h->ms_clean) HIPCHK(h, hipMemsetAsync(ms, 0, 3 * msn * sizeof(double), h->stream));
@@ -892,7 +917,7 @@ int icm_sweep_local(icm_handle* h) {
                 h->nchunks, h->chunk_group, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
                 h->rec_off.p, h->rec_off.p + nrec, h->rec_off.p + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->flags.p)));
             double* stats_mine = h->world > 1 ? stats_slot(h) : nullptr;
-            TIMED(h, KID_LM_L3, (k_lm_l3<<<(L + kWave - 1) / kWave, kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, h->new_rank.p + nloc, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p, h->ent_off.p + nloc, h->flags.p)));
+            TIMED(h, KID_LM_L3, (k_lm_l3<<<(L + kWave - 1) / kWave, kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, run_scan ? h->new_rank.p + nloc : h->flags.p + 9, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p, run_scan ? h->ent_off.p + nloc : h->flags.p + 8, h->flags.p)));
         }
         if (hier) {  // k_lm_l3 gathered the four words
             HIPCHK(h, hipMemcpyAsync(h->pin_i, h->flags.p + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -905,7 +930,7 @@ int icm_sweep_local(icm_handle* h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->pin_i[2] && h->hash_slots == 128) {  // a scan with > 96 distinct landmarks: use the larger table from now on
             h->hash_slots = 256;
-            HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 16 * sizeof(int), h->stream));
             continue;
         }
         break;
@@ -915,7 +940,7 @@ int icm_sweep_local(icm_handle* h) {
     if (h->optimistic && hier) {
         h->path_used = 1;
         if (h->world > 1)
-            k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, 0.0, 0.0, h->x, edge_first(h), edge_last(h), h->new_rank.p + nloc, h->flags.p);
+            k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, 0.0, 0.0, h->x, edge_first(h), edge_last(h), run_scan ? h->new_rank.p + nloc : h->flags.p + 9, h->flags.p);
         HIPCHK(h, hipGetLastError());
         return ICM_OK;
     }
@@ -1015,7 +1040,7 @@ int icm_sweep_targets(icm_handle* h) {
         HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
     }
     if (h->optimistic)   // the sweep's flags as every rank sees them (k_stats_prefix folded the other ranks' in)
-        HIPCHK(h, hipMemcpyAsync(h->pin_i + 12, h->flags.p, 3 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 12, h->flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));   // ([3]: poses outside their reserved staging place)
     if (h->path_used == 1) {  // next sweep's matrix: cleared here, under the solves (icm_sweep_finish waits for this stream)
         HIPCHK(h, hipMemsetAsync(h->ms.p, 0, 3 * (size_t)h->nsuper * (size_t)L * sizeof(double), h->copy_stream));
         h->ms_clean = true;
@@ -1144,13 +1169,21 @@ int icm_sweep_finish(icm_handle* h) {
     HIPCHK(h, hipEventSynchronize(h->ev_copied));  // the solves may still be running
     h->map_copy_pending = false;
     if (h->optimistic) {   // phase A's counts and flags, read only now (the copy was queued behind k_lm_l3)
-        h->E = h->pin_i[0];
+        if (h->scan_ran) h->E = h->pin_i[0];   // (a sweep without the scan kernels does not count its entries)
         h->n_new_loc = h->pin_i[1];
         // a table overflowed (here or, sharded, on any rank: the flags travelled with the statistics): poses and map
         // were left alone everywhere
-        if (h->pin_i[2] || (h->pin_i[3] & 1) || h->pin_i[12] || h->pin_i[13]) return ICM_RETRY_CAREFUL;
+        if (h->pin_i[2] || (h->pin_i[3] & 1) || h->pin_i[12] || h->pin_i[13]) {
+            h->scan_wanted = true;
+            return ICM_RETRY_CAREFUL;
+        }
         if (h->world == 1 && (int64_t)h->lact0 + h->n_new_loc > (int64_t)L)
             FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
+        // scan kernels in the next sweep?  (for a fresh reservation plan, while many poses do not fit the old one; the
+        // new landmarks' ranks k_chunk_l1 finds itself)
+        h->scan_wanted = (int64_t)h->pin_i[15] * 32 > h->nloc;
+    } else {
+        h->scan_wanted = true;
     }
     // total number of landmarks created this sweep, over all ranks
     int64_t n_new = h->n_new_loc;
@@ -1267,6 +1300,7 @@ int icm_restore_state(icm_handle* h) {
     hipStream_t st = h->stream;   // stream-ordered behind the last sweep: no synchronisation needed
     HIPCHK(h, hipMemcpyAsync(h->x, sn.x.p, 3 * T * sizeof(double), hipMemcpyDeviceToDevice, st));
     h->rot_valid = false;
+    h->scan_wanted = true;
     HIPCHK(h, hipMemcpyAsync(h->mapx.p, sn.mapx.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->mapy.p, sn.mapy.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->counts_new.p, sn.counts_new.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1375,7 +1409,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
     h->ms_clean = false;
     const SolveArgs sa = solve_args(h);
     GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p};
-    HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 8 * sizeof(int), X));
+    HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 16 * sizeof(int), X));
     for (int seg = 0; seg < 2; ++seg) {
         const int t0 = seg ? M : 0, t1 = seg ? nloc : M, nseg = t1 - t0;
         const int c0 = seg ? c_split : 0, c1 = seg ? NC : c_split;

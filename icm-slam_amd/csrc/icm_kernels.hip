@@ -680,7 +680,7 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int* __restrict__ isnew_out, int* __restrict__ flags,
                                                         const double* __restrict__ rot = nullptr, int nnz_total = 0,
                                                         int* __restrict__ st_off = nullptr, const int* __restrict__ plan = nullptr,
-                                                        int pose0 = 0, int sparse0 = 0) {
+                                                        int pose0 = 0, int sparse0 = 0, int no_scan = 0) {
     static_assert(PPW == 1 || (!PRELABEL && !DEBUG), "several poses per wave: plain configuration only");
     constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
     constexpr int kHashShift = HS == 128 ? 25 : 24;
@@ -881,6 +881,10 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         nent_out[tl] = written;
         st_off[tl] = sbase;
         isnew_out[tl] = anynew != 0ull;
+        // poses outside their reserved place: the host refreshes the plan when many (not counted while there is no plan
+        // at all -- the first sweep of a sequence: 100 000 atomics on one word)
+        if (!fits && plan1 > 0) atomicAdd(&flags[3], 1);
+
         if (overflow) flags[0] = 1;
     }
     if (DEBUG) {  // beam -> entry index within the pose
@@ -1201,7 +1205,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                                                      unsigned* __restrict__ pre_n, unsigned char* __restrict__ e_rec,
                                                      int* __restrict__ rec_label, double* __restrict__ rec_sx,
                                                      double* __restrict__ rec_sy, double* __restrict__ rec_n,
-                                                     int* __restrict__ flags, size_t dump, int c_begin = 0) {
+                                                     int* __restrict__ flags, size_t dump, int c_begin = 0,
+                                                     int* __restrict__ e_total = nullptr, const int* __restrict__ isnew = nullptr,
+                                                     unsigned long long* __restrict__ pub = nullptr, unsigned epoch = 0u,
+                                                     int spin_limit = 0) {
     __shared__ ChunkTable tables[kWavesPerBlock];
     const int lane = lane_id();
     const int c = c_begin + blockIdx.x * kWavesPerBlock + wave_in_block();   // chunks [c_begin, nchunks)
@@ -1222,8 +1229,57 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
         j0 = boff[tl];      // (the pose's place in the staging area: st_off)
         n = nent[tl];
         e0 = j0;            // the per-entry prefixes live at the entries' own places: no entry-offset scan needed for them
-        nr = new_rank[tl];
+        nr = e_total ? 0 : new_rank[tl];
         pose_of(x, x0, t_begin + tl, px, py, th);
+    }
+    if (e_total) {
+        // No scan kernels this sweep (the host keeps reporting the last scanned sweep's entry count: an atomic per chunk
+        // on one word to add it up here cost 9 us).  The ranks of the poses that create a landmark (their fresh labels: lact0 + number of such poses before) are the only thing
+        // the scan would still be needed for, and such poses are rare: every chunk PUBLISHES how many it has (one tagged
+        // 8-byte word, write-through; tag = this launch's epoch, so nothing is reset between launches), and only a chunk
+        // that has one adds up the words of the chunks before it.  Bounded polls: a word that does not arrive (a dispatch
+        // order that starts later chunks first on a chip too full to hold them all) raises flags[1]'s neighbour flags[0]
+        // -- nothing is then replaced and the host repeats the sweep with the scan kernels.
+        const int fl = (lane < kCH && tl < nloc) ? isnew[tl] : 0;
+        const unsigned long long fm = __ballot(fl != 0);
+        const int cnt = __popcll(fm);
+        if (lane == 0) {
+            if (cnt) atomicAdd(e_total + 1, cnt);   // (the sweep's new-landmark count; rare)
+            __hip_atomic_store(&pub[c], ((unsigned long long)epoch << 32) | (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (cnt) {   // (wave-uniform, rare)
+            int before = 0;
+            bool gave_up = false;
+            for (int q0 = 0; q0 < c; q0 += kWave * 8) {   // eight words per lane in flight
+                unsigned long long w[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) w[b] = __hip_atomic_load(&pub[min(q0 + b * kWave + lane, c - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int q = q0 + b * kWave + lane;
+                    if (q < c) {
+                        int spins = 0;
+                        while ((unsigned)(w[b] >> 32) != epoch) {
+                            if (++spins > spin_limit) {
+                                gave_up = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(4);
+                            w[b] = __hip_atomic_load(&pub[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        before += (int)(unsigned)w[b];
+                    }
+                }
+            }
+            if (__ballot(gave_up) != 0ull) {
+                for (int s = lane; s < kT1; s += kWave) rec_label[c * kT1 + s] = kEmpty;
+                if (lane == 0) flags[0] = 1;
+                return;
+            }
+#pragma unroll
+            for (int d = kWave / 2; d > 0; d >>= 1) before += __shfl_xor(before, d, kWave);
+            nr = before + prefix_count(fm, lane);
+        }
     }
     if (__ballot(n > kWave) != 0ull) {  // a scan with more than 64 distinct landmarks: the lanes of this
         for (int s = lane; s < kT1; s += kWave) rec_label[c * kT1 + s] = kEmpty;  // kernel map to entries
