@@ -866,7 +866,7 @@ int icm_sweep_local(icm_handle* h) {
     TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS, (PRE || DBG) ? 1 : ICM_ASSOC_PPW>                         \
         <<<nblocks_waves((nloc + ((PRE || DBG) ? 1 : ICM_ASSOC_PPW) - 1) / ((PRE || DBG) ? 1 : ICM_ASSOC_PPW)), kBlock, 0, h->stream>>>( \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
-        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->st_sparse0, run_scan ? 0 : 1)))
+        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->st_sparse0)))
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
     if (!h->rot_valid) {   // (the poses came from the host, a snapshot or a solve form that does not keep the table)
         TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p)));

@@ -680,7 +680,7 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int* __restrict__ isnew_out, int* __restrict__ flags,
                                                         const double* __restrict__ rot = nullptr, int nnz_total = 0,
                                                         int* __restrict__ st_off = nullptr, const int* __restrict__ plan = nullptr,
-                                                        int pose0 = 0, int sparse0 = 0, int no_scan = 0) {
+                                                        int pose0 = 0, int sparse0 = 0) {
     static_assert(PPW == 1 || (!PRELABEL && !DEBUG), "several poses per wave: plain configuration only");
     constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
     constexpr int kHashShift = HS == 128 ? 25 : 24;
@@ -1206,7 +1206,8 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                                                      int* __restrict__ rec_label, double* __restrict__ rec_sx,
                                                      double* __restrict__ rec_sy, double* __restrict__ rec_n,
                                                      int* __restrict__ flags, size_t dump, int c_begin = 0,
-                                                     int* __restrict__ e_total = nullptr, const int* __restrict__ isnew = nullptr,
+                                                     int* __restrict__ totals = nullptr,   /* non-null = no scan kernels this sweep: [1] += landmark-creating poses */
+                                                     const int* __restrict__ isnew = nullptr,
                                                      unsigned long long* __restrict__ pub = nullptr, unsigned epoch = 0u,
                                                      int spin_limit = 0) {
     __shared__ ChunkTable tables[kWavesPerBlock];
@@ -1229,10 +1230,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
         j0 = boff[tl];      // (the pose's place in the staging area: st_off)
         n = nent[tl];
         e0 = j0;            // the per-entry prefixes live at the entries' own places: no entry-offset scan needed for them
-        nr = e_total ? 0 : new_rank[tl];
+        nr = totals ? 0 : new_rank[tl];
         pose_of(x, x0, t_begin + tl, px, py, th);
     }
-    if (e_total) {
+    if (totals) {
         // No scan kernels this sweep (the host keeps reporting the last scanned sweep's entry count: an atomic per chunk
         // on one word to add it up here cost 9 us).  The ranks of the poses that create a landmark (their fresh labels: lact0 + number of such poses before) are the only thing
         // the scan would still be needed for, and such poses are rare: every chunk PUBLISHES how many it has (one tagged
@@ -1244,7 +1245,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
         const unsigned long long fm = __ballot(fl != 0);
         const int cnt = __popcll(fm);
         if (lane == 0) {
-            if (cnt) atomicAdd(e_total + 1, cnt);   // (the sweep's new-landmark count; rare)
+            if (cnt) atomicAdd(totals + 1, cnt);   // (the sweep's new-landmark count; rare)
             __hip_atomic_store(&pub[c], ((unsigned long long)epoch << 32) | (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (cnt) {   // (wave-uniform, rare)
