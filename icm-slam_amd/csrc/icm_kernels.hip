@@ -1287,13 +1287,14 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
         if (lane == 0) flags[1] = 1;                                               // -> sort-based path
         return;
     }
-    EntryGroup cur, nxt;
-    load_group(cur, 0, lane, n, j0, st_label, st_k, st_sbx, st_sby);
+    EntryGroup ga, gb;
+    load_group(ga, 0, lane, n, j0, st_label, st_k, st_sbx, st_sby);
     double ct, st;
     pose_rot(th, ct, st);
     __builtin_amdgcn_wave_barrier();
     bool overflow = false;
-    for (int p0 = 0; p0 < kCH && !overflow; p0 += kGroup) {
+    // one group of poses: `cur` is folded in while `nxt` fills (the two buffers swap roles from group to group, no copy)
+    auto fold_group = [&](EntryGroup& cur, EntryGroup& nxt, int p0) {
         // the next group's entries are in flight while this one is folded in
         if (p0 + kGroup < kCH) load_group(nxt, p0 + kGroup, lane, n, j0, st_label, st_k, st_sbx, st_sby);
         // 1. table slots of the group's entries: independent of the running sums, all at once
@@ -1333,10 +1334,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
         __builtin_amdgcn_wave_barrier();
         {
             const bool bad = T.used > kT1 - 32 || slot[0] < 0;
-            if (__ballot(bad) != 0ull) {  // too many distinct landmarks for the table: sort-based path
-                overflow = true;
-                break;
-            }
+            if (__ballot(bad) != 0ull) return true;   // too many distinct landmarks for the table: sort-based path
         }
         // 2. the poses in time order: running sums of their landmarks
 #pragma unroll
@@ -1367,7 +1365,12 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
             }
             __builtin_amdgcn_wave_barrier();
         }
-        cur = nxt;
+        return false;
+    };
+    static_assert((kCH / kGroup) % 2 == 0, "the groups of a chunk come in pairs");
+    for (int p0 = 0; p0 < kCH && !overflow; p0 += 2 * kGroup) {
+        overflow = fold_group(ga, gb, p0);
+        if (!overflow) overflow = fold_group(gb, ga, p0 + kGroup);
     }
     __builtin_amdgcn_wave_barrier();
     for (int s = lane; s < kT1; s += kWave) {
