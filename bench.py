@@ -285,19 +285,33 @@ def choose_collectives(args, rank, world, local_rank, dist):
     cfg = ConfigICM(D=dict(wl.config, schedule="redblack"))
     _, parts = partition(wl.T, world)
     a, b = parts[rank]
-    states = []
-    for kind in (LibrarySweep, ShardedSweep):
+
+    def three_sweeps(kind):
         eng = SweepEngine(cfg, local_rank)
-        eng.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
-        run = kind(eng, rank, world, wl.T)
-        run.set_state(wl.map_init, wl.x_init, wl.x0)
-        for _ in range(3):
-            run.sweep("redblack")
-        x, m, c, K = run.get_state()
-        states.append((x, m, c, K))
-        if hasattr(run, "close"):
-            run.close()
-        eng.close()
+        try:
+            eng.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
+            run = kind(eng, rank, world, wl.T)
+            try:
+                run.set_state(wl.map_init, wl.x_init, wl.x0)
+                for _ in range(3):
+                    run.sweep("redblack")
+                return run.get_state()
+            finally:
+                if hasattr(run, "close"):
+                    run.close()
+        finally:
+            eng.close()
+
+    # a library communicator that cannot be made (an RCCL build the wheel's torch does not share, a refused
+    # ncclCommInitRank) must not end the job: every rank then takes the torch path
+    states, why = [], ""
+    try:
+        states.append(three_sweeps(LibrarySweep))
+    except Exception as e:      # noqa: BLE001 -- whatever the library reports, the answer is "torch"
+        why = "%s: %s" % (type(e).__name__, e)
+    if not agree(len(states) == 1):
+        return "torch", "library collectives did not start on some rank" + (" (%s)" % why if why else "")
+    states.append(three_sweeps(ShardedSweep))
     same = states[0][3] == states[1][3] and all(np.array_equal(p, q) for p, q in zip(states[0][:3], states[1][:3]))
     if agree(same):
         return "library", "validated against the torch.distributed path on the tiny workload (3 sweeps, bit-identical)"
