@@ -5,7 +5,7 @@ sys.path.insert(0, 'icm-slam_amd'); sys.path.insert(0, '.')
 from icmslam_hip import _lib
 if os.environ.get("VLIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["VLIB"])
-import numpy as np, time
+import numpy as np, time, zlib
 from ICM_SLAM_tools import ConfigICM
 from icmslam_hip import SweepEngine
 from icmslam_hip.synthetic import WORKLOADS, make_workload
@@ -26,5 +26,5 @@ for mode in [int(a) for a in sys.argv[1:]] or [0, 1]:
     kt = eng.kernel_times(); eng.enable_timing(False)
     x = eng.get_state()[0]
     if ref is None: ref = x
-    print(os.environ.get("VLIB", "default"), "lanes-mode", mode, "ms/sweep %.4f" % ms, "k_solve", kt.get("k_solve"), "k_assoc", kt.get("k_assoc_group"), "l1", round(kt["k_chunk_l1"][0]/kt["k_chunk_l1"][1],4), "moments", round(kt["k_pose_moments"][0]/kt["k_pose_moments"][1],4), "l2/l3/push", [round(kt[k][0]/kt[k][1],4) for k in ("k_chunk_l2","k_lm_l3","k_rec_push")], "same", bool(np.array_equal(x, ref)), flush=True)
+    print(os.environ.get("VLIB", "default"), "lanes-mode", mode, "ms/sweep %.4f" % ms, "k_solve", kt.get("k_solve"), "k_assoc", kt.get("k_assoc_group"), "l1", round(kt["k_chunk_l1"][0]/kt["k_chunk_l1"][1],4), "moments", round(kt["k_pose_moments"][0]/kt["k_pose_moments"][1],4), "l2/l3/push", [round(kt[k][0]/kt[k][1],4) for k in ("k_chunk_l2","k_lm_l3","k_rec_push")], "same", bool(np.array_equal(x, ref)), "crc %08x" % zlib.crc32(np.ascontiguousarray(x).tobytes()), flush=True)
 eng.close()
