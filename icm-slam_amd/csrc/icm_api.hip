@@ -513,9 +513,9 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->st_off.reserve((size_t)nloc + 1));
     h->st_stride = nst + kWave;
     HIPCHK(h, h->btx.reserve(nz)); HIPCHK(h, h->bty.reserve(nz));
-    HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(std::max<size_t>(nz + kWave, (h->st_stride + 3) / 4 + kWave)));
+    HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz + kWave));
     HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_b.reserve(nz));
-    // (e_w also holds the three per-entry prefix arrays of the hierarchical path, e_val its record ids: one per staging place)
+    // (e_w also holds the three per-entry prefix arrays of the hierarchical path: one element per staging place)
     HIPCHK(h, h->e_w.reserve(std::max<size_t>(nz + kWave, (3 * h->st_stride * sizeof(double) + sizeof(EntW) - 1) / sizeof(EntW) + kWave)));
     HIPCHK(h, h->e_wr.reserve(nz)); HIPCHK(h, h->tgt.reserve(nz));
     HIPCHK(h, h->scan_tot.reserve(2 * ((size_t)nloc / kScanTile + 2)));
@@ -906,7 +906,6 @@ int icm_sweep_local(icm_handle* h) {
     TIMED(h, KID_CHUNK_L1, (k_chunk_l1<CH><<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(                          \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->st_off.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0, \
         h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, reinterpret_cast<unsigned*>(pre + 2 * nzs),        \
-        reinterpret_cast<unsigned char*>(h->e_val.p),                                                                   \
         h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave, 0,          \
         run_scan ? nullptr : h->flags.p + 8, h->isnew.p, h->chunk_pub.p, h->scan_epoch, 1 << 16)))
             if (h->chunk_poses == 64) CHUNK_L1(64); else if (h->chunk_poses == 32) CHUNK_L1(32); else CHUNK_L1(16);
@@ -1008,7 +1007,7 @@ int icm_sweep_targets(icm_handle* h) {
             ro, ro + nrec, ro + 2 * (size_t)nrec)));
         TIMED(h, KID_POSE_MOMENTS, (k_pose_moments_h<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(
             h->x, h->x0.p, (int)h->t_begin, nloc, h->st_off.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p,
-            pre, pre + nzs, reinterpret_cast<const unsigned*>(pre + 2 * nzs), reinterpret_cast<const unsigned char*>(h->e_val.p), h->chunk_poses,
+            pre, pre + nzs, reinterpret_cast<const unsigned*>(pre + 2 * nzs), h->chunk_poses,
             ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr, 0, -1, h->rot.p)));
     } else if (h->world > 1) {
         TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
@@ -1432,7 +1431,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
 #define CHUNK_L1(CHV)                                                                                                  \
     k_chunk_l1<CHV><<<nblocks_waves(c1 - c0), kBlock, 0, X>>>(h->x, h->x0.p, 0, nloc, c1, h->st_off.p, h->nent.p, h->ent_off.p, \
         h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs,                          \
-        reinterpret_cast<unsigned*>(pre + 2 * nzs), reinterpret_cast<unsigned char*>(h->e_val.p), h->rec_label.p, h->rec_s.p, \
+        reinterpret_cast<unsigned*>(pre + 2 * nzs), h->rec_label.p, h->rec_s.p, \
         h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - kWave, c0)
         if (CH == 64) CHUNK_L1(64); else if (CH == 32) CHUNK_L1(32); else CHUNK_L1(16);
 #undef CHUNK_L1
@@ -1446,7 +1445,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
                                                                                nullptr, nullptr, nullptr, ro, ro + nrec, ro + 2 * (size_t)nrec, c0 * kT1);
         k_pose_moments_h<<<nblocks_threads((int64_t)nseg * 16), kBlock, 0, X>>>(
             h->x, h->x0.p, 0, nloc, h->st_off.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, pre, pre + nzs,
-            reinterpret_cast<const unsigned*>(pre + 2 * nzs), reinterpret_cast<const unsigned char*>(h->e_val.p), CH, ro, ro + nrec,
+            reinterpret_cast<const unsigned*>(pre + 2 * nzs), CH, ro, ro + nrec,
             ro + 2 * (size_t)nrec, h->pose_m.p, nullptr, t0, t1, h->rot.p);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipEventRecord(h->ev_m[seg], X));

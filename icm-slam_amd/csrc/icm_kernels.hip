@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_prefix(const double* __restric
 // ---------------------------------------------------------------------------------------
 constexpr int kCHMax = 64;       // poses per chunk: 64, 32 or 16 (lane p holds pose p's header); short
                                  // sequences use short chunks -- a chunk is ONE wave's serial work
-constexpr int kT1 = 256;         // slots of a chunk table
+constexpr int kT1 = 256;         // slots of a chunk table (a slot index is one byte: k_chunk_l1 packs it beside the entry's count)
 constexpr int kT2 = 2048;        // slots of a superchunk table
 constexpr int kT2Cap = 1536;
 constexpr int kMaxSuper = 64;    // rows of the dense matrix
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                                                      const int* __restrict__ st_label, const int* __restrict__ st_k,
                                                      const double* __restrict__ st_sbx, const double* __restrict__ st_sby,
                                                      double* __restrict__ pre_x, double* __restrict__ pre_y,
-                                                     unsigned* __restrict__ pre_n, unsigned char* __restrict__ e_rec,
+                                                     unsigned* __restrict__ pre_n,
                                                      int* __restrict__ rec_label, double* __restrict__ rec_sx,
                                                      double* __restrict__ rec_sy, double* __restrict__ rec_n,
                                                      int* __restrict__ flags, size_t dump, int c_begin = 0,
@@ -1360,8 +1360,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                 const size_t o = act ? (size_t)(ep + lane) : dump + lane;
                 pre_x[o] = ax;
                 pre_y[o] = ay;
-                pre_n[o] = (unsigned)an;          // (a count of beams: exact, < 2^32 -- checked at upload)
-                e_rec[o] = (unsigned char)sl;     // slot; the chunk follows from the pose
+                // beams of the landmark inside the chunk through this pose (exact; at most 64 poses x 8192 beams < 2^24, both
+                // bounds checked at upload) and, in the low byte, the slot of the entry's record (the chunk follows from
+                // the pose): one word
+                pre_n[o] = ((unsigned)an << 8) | ((unsigned)sl & 255u);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -2209,7 +2211,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
                                                            const double* __restrict__ st_sby,
                                                            const double* __restrict__ pose_s2,
                                                            const double* __restrict__ pre_x, const double* __restrict__ pre_y,
-                                                           const unsigned* __restrict__ pre_n, const unsigned char* __restrict__ e_rec, int chunk_poses,
+                                                           const unsigned* __restrict__ pre_n, int chunk_poses,
                                                            const double* __restrict__ off_x, const double* __restrict__ off_y,
                                                            const double* __restrict__ off_n, double* __restrict__ pose_m,
                                                            double2* __restrict__ tgt_out, int tl_begin = 0, int tl_end = -1,
@@ -2239,8 +2241,9 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
     double mxx = 0.0, mxy = 0.0, myy = 0.0;
     for (int q = sub; q < n; q += 16) {
         const double k = (double)st_k[j0 + q], sbx = st_sbx[j0 + q], sby = st_sby[j0 + q];
-        const int r = (tl / chunk_poses) * kT1 + (int)e_rec[e0 + q];
-        const double sx = off_x[r] + pre_x[e0 + q], sy = off_y[r] + pre_y[e0 + q], sn = off_n[r] + (double)pre_n[e0 + q];
+        const unsigned nw = pre_n[e0 + q];   // (beams inside the chunk through this pose) << 8 | record slot
+        const int r = (tl / chunk_poses) * kT1 + (int)(nw & 255u);
+        const double sx = off_x[r] + pre_x[e0 + q], sy = off_y[r] + pre_y[e0 + q], sn = off_n[r] + (double)(nw >> 8);
         const double tx = sx / sn, ty = sy / sn;
         if (tgt_out) tgt_out[et + q] = make_double2(tx, ty);   // association dump (icm_set_debug)
         const double wx = (ct * sbx - st * sby) / k, wy = (st * sbx + ct * sby) / k;
