@@ -55,18 +55,18 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True):
     group = (nchunks + 63) // 64
     nsuper = (nchunks + group - 1) // max(group, 1)
     per_sweep = {
-        # staged entry in (label 4, k 4, sum bx 8, sum by 8); prefix (sum x 8, sum y 8, one word of n and the
+        # staged entry in (label 4, k 2, sum bx 8, sum by 8); prefix (sum x 8, sum y 8, one word of n and the
         # record slot 4) out; per pose: offsets 16 + pose 24; per chunk: 256 record labels
-        "k_chunk_l1": E * 24 + E * 20 + nloc * 40 + nchunks * 256 * 4,
+        "k_chunk_l1": E * 22 + E * 20 + nloc * 40 + nchunks * 256 * 4,
         # dense [superchunks x L] matrix of (sx, sy, n): read once, written once
         "k_lm_l3": 2 * 3 * 8 * nsuper * L + L * 24,
         # read body x,y of every kept beam (16 B) + pose; write one staged entry
-        # (label 4, k 4, sum bx 8, sum by 8) per distinct landmark of the scan; counts/flags
-        "k_assoc_group": nnz * 16 + E * 24 + nloc * (24 + 8 + 8),
+        # (label 4, k 2, sum bx 8, sum by 8) per distinct landmark of the scan; counts/flags
+        "k_assoc_group": nnz * 16 + E * 22 + nloc * (24 + 8 + 8),
         "k_associate_brute": nnz * (16 + 4) + nloc * 32,
-        # staged entries in (24); out: key 4, id 4, k 4, world sums 32, rotated mean offset 16;
+        # staged entries in (22); out: key 4, id 4, k 4, world sums 32, rotated mean offset 16;
         # per pose: pose 24, second moments 24, scatter 24, offsets 8
-        "k_compact": E * 24 + E * 60 + nloc * 80,
+        "k_compact": E * 22 + E * 60 + nloc * 80,
         "radix_sort_pairs": E * 8 * 2 * 2,
         "k_lm_bounds": (L + 1) * 4,
         "k_lm_scan_totals": E * (4 + 32) + L * (8 + 24),
@@ -75,8 +75,8 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True):
         "k_lm_scan": E * (4 + 32 + 16) + L * (8 + 24),
         "k_beam_targets": nnz * (4 + 16) + E * 16,
         # per entry: k 4, rotated mean 16, target 16; per pose: pose 24, scatter 24, 17 moments out
-        # hierarchical pipeline: staged k + sums 20, prefix + record slot 20, record prefix 24 (L2-resident gather)
-        "k_pose_moments": (E * (20 + 20 + 24) if hier else E * 36) + nloc * (24 + 24 + 136 + 8),
+        # hierarchical pipeline: staged k + sums 18, prefix + record slot 20, record prefix 24 (L2-resident gather)
+        "k_pose_moments": (E * (18 + 20 + 24) if hier else E * 36) + nloc * (24 + 24 + 136 + 8),
         # both colours together, per pose: 17 moments, own + 2 neighbour poses, odometry 72, u 32, pose out 24
         "k_solve": nloc * (136 + 72 + 72 + 32 + 24 + 8),
         "k_scan": nloc * 16,

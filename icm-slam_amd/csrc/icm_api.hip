@@ -101,7 +101,8 @@ struct icm_handle {
     DevBuf<double> mapx, mapy;
 
     // per-sweep
-    DevBuf<int> label, bloc, st_label, st_k, nent, isnew, ent_off, new_rank, e_val, e_k, sval, lm_off, flags, scan_tot;
+    DevBuf<unsigned short> st_k;    // beams of every staged entry (<= B <= 8192: two bytes)
+    DevBuf<int> label, bloc, st_label, nent, isnew, ent_off, new_rank, e_val, e_k, sval, lm_off, flags, scan_tot;
     DevBuf<unsigned> e_key, skey;
     DevBuf<double> st_sx, st_sy, pose_c, pose_m, btx, bty;
     DevBuf<double2> e_b, e_wr, tgt;
@@ -354,10 +355,10 @@ int icm_destroy(icm_handle* h) {
                             &h->mapx, &h->mapy, &h->st_sx, &h->st_sy, &h->pose_m, &h->pose_c, &h->pose_s2, &h->btx, &h->bty, &h->stats_own, &h->off_sx, &h->off_sy, &h->off_n, &h->y_raw,
                             &h->cnt_raw, &h->diag};
     for (auto* b : dd) b->release();
-    DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->label, &h->bloc, &h->st_label, &h->st_k,
+    DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->label, &h->bloc, &h->st_label,
                          &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags, &h->scan_tot};
     for (auto* b : di) b->release();
-    h->g_lm.release(); h->gpar.release(); h->g_nb.release();
+    h->g_lm.release(); h->gpar.release(); h->g_nb.release(); h->st_k.release();
     h->fl_nn.release(); h->fl_lab.release(); h->fl_comp.release(); h->fl_csize.release(); h->fl_isl.release(); h->fl_rank.release();
     h->fl_scan_tot.release(); h->fl_state.release(); h->fl_nd.release();
     h->fl_cid.release(); h->fl_cell_cnt.release(); h->fl_cell_fill.release(); h->fl_info.release();

@@ -675,7 +675,7 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         const double* __restrict__ bx, const double* __restrict__ by,
                                                         GridView g, double thr, double thr2, int* __restrict__ label,
                                                         int* __restrict__ bloc, int* __restrict__ st_label,
-                                                        int* __restrict__ st_k, double* __restrict__ st_sbx,
+                                                        unsigned short* __restrict__ st_k, double* __restrict__ st_sbx,
                                                         double* __restrict__ st_sby, int* __restrict__ nent_out,
                                                         int* __restrict__ isnew_out, int* __restrict__ flags,
                                                         const double* __restrict__ rot = nullptr, int nnz_total = 0,
@@ -868,7 +868,7 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         if (occ) {
             const unsigned q = (unsigned)(written + prefix_count(mask, lane));   // (scalar bases + 32-bit offsets, like the beam loads)
             *reinterpret_cast<int*>(reinterpret_cast<char*>(st_label + sbase) + (q << 2)) = k;
-            *reinterpret_cast<int*>(reinterpret_cast<char*>(st_k + sbase) + (q << 2)) = T.cnt[s];
+            *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(st_k + sbase) + (q << 1)) = (unsigned short)T.cnt[s];   // (beams of one scan: <= B <= 8192)
             *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sbx + sbase) + (q << 3)) = T.sx[s];
             *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sby + sbase) + (q << 3)) = T.sy[s];
             isnew |= k == -1;
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(const double* __restrict__ x
                                                     int t_begin, int nloc, const int* __restrict__ boff,
                                                     const int* __restrict__ ent_off, const int* __restrict__ new_rank,
                                                     int lact0, const int* __restrict__ st_label,
-                                                    const int* __restrict__ st_k, const double* __restrict__ st_sbx,
+                                                    const unsigned short* __restrict__ st_k, const double* __restrict__ st_sbx,
                                                     const double* __restrict__ st_sby, const double* __restrict__ pose_s2,
                                                     unsigned* __restrict__ e_key, int* __restrict__ e_val,
                                                     int* __restrict__ e_k, double2* __restrict__ e_b,
@@ -1178,7 +1178,7 @@ struct EntryGroup {
 };
 
 __device__ __forceinline__ void load_group(EntryGroup& g, int p0, int lane, int n, int j0, const int* __restrict__ st_label,
-                                           const int* __restrict__ st_k, const double* __restrict__ st_sbx,
+                                           const unsigned short* __restrict__ st_k, const double* __restrict__ st_sbx,
                                            const double* __restrict__ st_sby) {
 #pragma unroll
     for (int i = 0; i < kGroup; ++i) {
@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                                                      int t_begin, int nloc, int nchunks, const int* __restrict__ boff,
                                                      const int* __restrict__ nent, const int* __restrict__ ent_off,
                                                      const int* __restrict__ new_rank, int lact0,
-                                                     const int* __restrict__ st_label, const int* __restrict__ st_k,
+                                                     const int* __restrict__ st_label, const unsigned short* __restrict__ st_k,
                                                      const double* __restrict__ st_sbx, const double* __restrict__ st_sby,
                                                      double* __restrict__ pre_x, double* __restrict__ pre_y,
                                                      unsigned* __restrict__ pre_n,
@@ -2207,7 +2207,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments(const double* __restric
 __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restrict__ x, const double* __restrict__ x0,
                                                            int t_begin, int nloc, const int* __restrict__ boff,
                                                            const int* __restrict__ nent, const int* __restrict__ ent_off,
-                                                           const int* __restrict__ st_k, const double* __restrict__ st_sbx,
+                                                           const unsigned short* __restrict__ st_k, const double* __restrict__ st_sbx,
                                                            const double* __restrict__ st_sby,
                                                            const double* __restrict__ pose_s2,
                                                            const double* __restrict__ pre_x, const double* __restrict__ pre_y,
