@@ -1133,6 +1133,7 @@ constexpr int kT1 = 256;         // slots of a chunk table (a slot index is one 
 constexpr int kT2 = 2048;        // slots of a superchunk table
 constexpr int kT2Cap = 1536;
 constexpr int kMaxSuper = 64;    // rows of the dense matrix
+constexpr int kDumpRows = 1024;  // 64-entry rows behind the per-entry prefix arrays that take the idle lanes' stores
 
 struct ChunkTable {
     int key[kT1];
@@ -1183,9 +1184,10 @@ __device__ __forceinline__ void load_group(EntryGroup& g, int p0, int lane, int 
 #pragma unroll
     for (int i = 0; i < kGroup; ++i) {
         const int np = lane_bcast(n, p0 + i), jp = lane_bcast(j0, p0 + i);
-        // every lane loads (idle lanes re-read staged entry 0): no branch around the loads, so the
-        // compiler can count them and wait for exactly the group it is about to use
-        const int j = lane < np ? jp + lane : 0;
+        // every lane loads (idle lanes re-read the pose's last entry -- a line the active lanes fetch anyway, not one
+        // address that every wave of the launch would share): no branch around the loads, so the compiler can count
+        // them and wait for exactly the group it is about to use
+        const int j = jp + min(lane, max(np - 1, 0));
         const int lab = st_label[j];
         g.lab[i] = lane < np ? lab : kEmpty;
         g.k[i] = st_k[j];
@@ -1356,8 +1358,9 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                 T.sx[sl] = ax;
                 T.sy[sl] = ay;
                 T.sn[sl] = an;
-                // idle lanes store to the dump row behind the entries (no branch around the stores either)
-                const size_t o = act ? (size_t)(ep + lane) : dump + lane;
+                // idle lanes store to a dump row behind the entries (no branch around the stores either) -- one of
+                // kDumpRows rows by chunk: a single row would be the same four lines of L2 for every wave of the launch
+                const size_t o = act ? (size_t)(ep + lane) : dump + (size_t)((c & (kDumpRows - 1)) * kWave + lane);
                 pre_x[o] = ax;
                 pre_y[o] = ay;
                 // beams of the landmark inside the chunk through this pose (exact; at most 64 poses x 8192 beams < 2^24, both
