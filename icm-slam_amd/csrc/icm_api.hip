@@ -115,7 +115,7 @@ struct icm_handle {
     int nchunks = 0, chunk_poses = 64, chunk_group = 1, nsuper = 0;
     DevBuf<int> st_off;      // where each pose's staged entries start (k_assoc_group: packed area or sparse area)
     int64_t st_sparse0 = 0;  // first entry of the sparse area (behind the packed one)
-    size_t st_stride = 0;    // entries of the staging area (+ the dump rows): stride of the per-entry prefix arrays
+    size_t st_stride = 0;    // entries of the staging area: stride of the per-entry prefix arrays
     // icm_snapshot_state / icm_restore_state: device copy of the sweep state (poses, map, search structures)
     struct Snapshot {
         DevBuf<double> x, mapx, mapy, counts_new;
@@ -512,7 +512,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->label.reserve(nz)); HIPCHK(h, h->bloc.reserve(nz)); HIPCHK(h, h->st_label.reserve(nst));
     HIPCHK(h, h->st_k.reserve(nst)); HIPCHK(h, h->st_sx.reserve(nst)); HIPCHK(h, h->st_sy.reserve(nst));
     HIPCHK(h, h->st_off.reserve((size_t)nloc + 1));
-    h->st_stride = nst + (size_t)kDumpRows * kWave;
+    h->st_stride = nst + kWave;
     HIPCHK(h, h->btx.reserve(nz)); HIPCHK(h, h->bty.reserve(nz));
     HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz + kWave));
     HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_b.reserve(nz));
@@ -888,7 +888,7 @@ int icm_sweep_local(icm_handle* h) {
     h->scan_ran = run_scan;
     const int nrec = h->nchunks * kT1;
     double* const pre = reinterpret_cast<double*>(h->e_w.p);   // [3][nnz] (the sort-based path's record buffer)
-    const size_t nzs = h->st_stride;   // + the dump rows of k_chunk_l1
+    const size_t nzs = h->st_stride;
     double* const ms = h->ms.p;
     const size_t msn = (size_t)h->nsuper * (size_t)L;
     for (;;) {
@@ -907,7 +907,7 @@ int icm_sweep_local(icm_handle* h) {
     TIMED(h, KID_CHUNK_L1, (k_chunk_l1<CH><<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(                          \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->st_off.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0, \
         h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, reinterpret_cast<unsigned*>(pre + 2 * nzs),        \
-        h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - (size_t)kDumpRows * kWave, 0, \
+        h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, 0,                           \
         run_scan ? nullptr : h->flags.p + 8, h->isnew.p, h->chunk_pub.p, h->scan_epoch, 1 << 16)))
             if (h->chunk_poses == 64) CHUNK_L1(64); else if (h->chunk_poses == 32) CHUNK_L1(32); else CHUNK_L1(16);
 #undef CHUNK_L1
@@ -1433,7 +1433,7 @@ static int icm_sweep_pipelined(icm_handle* h) {
     k_chunk_l1<CHV><<<nblocks_waves(c1 - c0), kBlock, 0, X>>>(h->x, h->x0.p, 0, nloc, c1, h->st_off.p, h->nent.p, h->ent_off.p, \
         h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs,                          \
         reinterpret_cast<unsigned*>(pre + 2 * nzs), h->rec_label.p, h->rec_s.p, \
-        h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, nzs - (size_t)kDumpRows * kWave, c0)
+        h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, c0)
         if (CH == 64) CHUNK_L1(64); else if (CH == 32) CHUNK_L1(32); else CHUNK_L1(16);
 #undef CHUNK_L1
         k_chunk_l2<<<s1 - s0, kT1, 0, X>>>(NC, G, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,

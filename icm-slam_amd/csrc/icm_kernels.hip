@@ -1133,7 +1133,7 @@ constexpr int kT1 = 256;         // slots of a chunk table (a slot index is one 
 constexpr int kT2 = 2048;        // slots of a superchunk table
 constexpr int kT2Cap = 1536;
 constexpr int kMaxSuper = 64;    // rows of the dense matrix
-constexpr int kDumpRows = 1024;  // 64-entry rows behind the per-entry prefix arrays that take the idle lanes' stores
+constexpr int kRawBuffer = 0x00020000;   // dword 3 of a raw (stride 0) buffer descriptor on gfx9 / CDNA: 32-bit data format
 
 struct ChunkTable {
     int key[kT1];
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                                                      unsigned* __restrict__ pre_n,
                                                      int* __restrict__ rec_label, double* __restrict__ rec_sx,
                                                      double* __restrict__ rec_sy, double* __restrict__ rec_n,
-                                                     int* __restrict__ flags, size_t dump, int c_begin = 0,
+                                                     int* __restrict__ flags, int c_begin = 0,
                                                      int* __restrict__ totals = nullptr,   /* non-null = no scan kernels this sweep: [1] += landmark-creating poses */
                                                      const int* __restrict__ isnew = nullptr,
                                                      unsigned long long* __restrict__ pub = nullptr, unsigned epoch = 0u,
@@ -1358,15 +1358,16 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
                 T.sx[sl] = ax;
                 T.sy[sl] = ay;
                 T.sn[sl] = an;
-                // idle lanes store to a dump row behind the entries (no branch around the stores either) -- one of
-                // kDumpRows rows by chunk: a single row would be the same four lines of L2 for every wave of the launch
-                const size_t o = act ? (size_t)(ep + lane) : dump + (size_t)((c & (kDumpRows - 1)) * kWave + lane);
-                pre_x[o] = ax;
-                pre_y[o] = ay;
-                // beams of the landmark inside the chunk through this pose (exact; at most 64 poses x 8192 beams < 2^24, both
-                // bounds checked at upload) and, in the low byte, the slot of the entry's record (the chunk follows from
-                // the pose): one word
-                pre_n[o] = ((unsigned)an << 8) | ((unsigned)sl & 255u);
+                // One buffer descriptor per array spans exactly this pose's np entries: the hardware drops the stores of the
+                // lanes beyond it (raw buffer addressing, offset >= range) -- no branch around the stores, so the compiler
+                // still counts them exactly, and no idle-lane traffic at all.
+                // (beams of the landmark inside the chunk through this pose -- exact; at most 64 poses x 8192 beams < 2^24,
+                // both bounds checked at upload -- and, in the low byte, the slot of the entry's record: one word)
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const int off8 = lane << 3;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ax), __builtin_amdgcn_make_buffer_rsrc(pre_x + ep, 0, np << 3, kRawBuffer), off8, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ay), __builtin_amdgcn_make_buffer_rsrc(pre_y + ep, 0, np << 3, kRawBuffer), off8, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(((unsigned)an << 8) | ((unsigned)sl & 255u), __builtin_amdgcn_make_buffer_rsrc(pre_n + ep, 0, np << 2, kRawBuffer), lane << 2, 0, 0);
             }
             __builtin_amdgcn_wave_barrier();
         }
