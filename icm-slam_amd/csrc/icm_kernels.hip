@@ -1383,11 +1383,9 @@ __global__ __launch_bounds__(kBlock) void k_chunk_l1(const double* __restrict__ 
         const int r = c * kT1 + s;
         const int k = overflow ? kEmpty : T.key[s];
         rec_label[r] = k;
-        if (k != kEmpty) {
-            rec_sx[r] = T.sx[s];
-            rec_sy[r] = T.sy[s];
-            rec_n[r] = T.sn[s];
-        }
+        rec_sx[r] = T.sx[s];   // (unused slots hold zeros: whole lines go out, and k_chunk_l2 reads every slot anyway)
+        rec_sy[r] = T.sy[s];
+        rec_n[r] = T.sn[s];
     }
     if (overflow && lane == 0) flags[1] = 1;
 }
