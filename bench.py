@@ -13,8 +13,9 @@ Poses are solved in the red-black order (the reference's sequential order is one
 chain of T-1 solves and is used for parity, not throughput).
 
 N > 1 (BASELINE.json configs[4]): the fixed S2 sequence is sharded by contiguous pose blocks
-over the ranks ("scaling": "strong"), one all-gather of the landmark sufficient statistics and
-one 48-byte halo all-gather per sweep.  The same job is then repeated on a sequence N times as
+over the ranks ("scaling": "strong"), ONE all-gather per sweep (landmark sufficient statistics +
+the shards' boundary poses; each shard solves the pose in front of it as a ghost pose instead of
+exchanging a halo between the colours).  The same job is then repeated on a sequence N times as
 long (every GPU owns a 100k-pose block: fixed work per GPU) and reported as the secondary
 record `"weak"` of the same JSON line.  `--scaling weak` swaps the two.
 
@@ -180,7 +181,8 @@ class Job:
         from icmslam_hip.synthetic import make_workload
         self.args, self.dist, self.world, self.rank, self.sharded = args, dist, world, rank, sharded
         self.T, self.K, self.B = T, K, B
-        self.blk = (T + world - 1) // world
+        from icmslam_hip.sharded import shard_block
+        self.blk = shard_block(T, world)          # ceil(T / world) rounded up to an even number of poses
         self.t_begin, self.t_end = min(rank * self.blk, T), min((rank + 1) * self.blk, T)
         t0 = time.perf_counter()
         self.wl = wl = make_workload(T, K, B, t_begin=self.t_begin, t_end=self.t_end)
@@ -192,9 +194,8 @@ class Job:
         else:
             from icmslam_hip import SweepEngine
             self.eng = eng = SweepEngine(cfg, local_rank)
-            if args.pipeline:
-                eng.set_pipeline(True)
-            eng.upload(wl.scans, wl.odometry, wl.u, t_begin=self.t_begin, t_end=self.t_end, pose_major=True)
+            eng.upload(wl.scans, wl.odometry, wl.u, t_begin=self.t_begin, t_end=self.t_end, pose_major=True,
+                       ghost_scan=wl.ghost_scan if (sharded and rank > 0) else None)
         self.t_upload = time.perf_counter() - t0
         if sharded:
             from icmslam_hip.sharded import LibrarySweep, ShardedSweep
@@ -234,11 +235,9 @@ class Job:
                 import torch
                 torch.cuda.synchronize()
 
-    def timed(self, steps, warmup):
-        """W untimed sweeps, then exactly K sweeps between two (barrier + device synchronise) fences;
-        the MAX over ranks of the elapsed time."""
-        for _ in range(warmup):
-            self.step()
+    def window(self, steps):
+        """Exactly `steps` sweeps between two (barrier + device synchronise) fences; the MAX over ranks of the
+        elapsed time."""
         self.fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -252,6 +251,25 @@ class Job:
             elapsed = float(tt.item())
         return elapsed
 
+    def timed(self, steps, warmup, windows=1):
+        """W untimed sweeps, then `windows` timed windows of exactly K sweeps each.  Every window sweeps the SAME
+        states: the state after the warm-up is snapshotted on the device and put back (device-to-device copies,
+        outside the timed regions) before each further window, followed by one untimed sweep so that every window
+        starts with the steady-state launch sequence.  Returns the list of elapsed times."""
+        for _ in range(warmup):
+            self.step()
+        can_rewind = windows > 1 and hasattr(self.eng, "snapshot_state") and not self.rewind
+        if can_rewind:
+            self.fence()
+            self.eng.snapshot_state()
+            self.step()                       # (the same untimed sweep precedes every window)
+        out = [self.window(steps)]
+        for _ in range(windows - 1 if can_rewind else 0):
+            self.eng.restore_state()
+            self.step()
+            out.append(self.window(steps))
+        return out
+
     def close(self):
         if hasattr(getattr(self, "runner", None), "close"):
             self.runner.close()
@@ -260,7 +278,7 @@ class Job:
 
 
 def choose_collectives(args, rank, world, local_rank, dist):
-    """Who issues the two all-gathers of a sharded sweep.  "library": the C library itself (RCCL on the
+    """Who issues the all-gather of a sharded sweep.  "library": the C library itself (RCCL on the
     handle's stream, one C call per sweep) -- taken when every rank resolves an RCCL library AND three
     sweeps of the `tiny` workload give bit for bit the state the torch.distributed path gives;
     otherwise "torch" (all_gather_into_tensor from Python).  Both are the product path."""
@@ -289,7 +307,7 @@ def choose_collectives(args, rank, world, local_rank, dist):
     def three_sweeps(kind):
         eng = SweepEngine(cfg, local_rank)
         try:
-            eng.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
+            eng.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.scans[a - 1] if a else None)
             run = kind(eng, rank, world, wl.T)
             try:
                 run.set_state(wl.map_init, wl.x_init, wl.x0)
@@ -318,16 +336,26 @@ def choose_collectives(args, rank, world, local_rank, dist):
     return "torch", "library collectives disagreed with torch.distributed on the tiny workload"
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json), and the file it was
+    made from; (None, None) without one.  Only for a one-GPU run of the full workload (that is what was profiled)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return int(tj[workload][kernel]), tj.get("_source", {}).get(workload)
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
+
+
 def roofline(job, ms_per_step):
     """Per-kernel launch times from HIP events on the launch stream (icm_enable_timing), over
     three more sweeps; achieved = algorithmic bytes (or flops) per launch / average launch time."""
     eng, args = job.eng, job.args
-    st = eng.last_stats()
     eng.enable_timing(True)
     nroof = 3
     for _ in range(nroof):
         job.inner()
     job.fence()
+    st = eng.last_stats()      # (after the timing sweeps: they run the entry-offset scan, so the entry count is theirs)
     kt = {k: v for k, v in eng.kernel_times().items() if v[1] > 0 and k != "k_prefilter"}
     hier = eng.entry_path() == "hier"
     eng.enable_timing(False)
@@ -348,11 +376,13 @@ def roofline(job, ms_per_step):
         ms_k, n_k = kt[kname]
         ab = ab_of(kname, n_k)
         a_gbs = ab / (ms_k / n_k * 1e-3) / 1e9
-        # `traffic` is a PMC quantity (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile.sh):
-        # it cannot be collected from inside this process, so it is null here; the committed PMC
-        # summaries of this build are under profiles/ (r02_*_pmc_traffic_*.csv)
+        # `traffic` is a PMC quantity (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile.sh): it cannot
+        # be collected from inside this process.  The number reported is the one the committed PMC summary of this
+        # kernel holds (profiles/traffic.json, written by tools/pmc_summary.py --traffic from the same workload's
+        # passes; `traffic_source` names the summary file it came from), null when there is none for this workload.
+        tr, src = pmc_traffic(args.workload, kname)
         return {"bound": "hbm", "kernel": kname, "achieved": round(a_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(a_gbs / HBM_PEAK_GBS, 5), "traffic": tr, "traffic_source": src,
                 "avg_launch_ms": round(ms_k / n_k, 4), "launches_per_sweep": n_k / nroof,
                 "algorithmic_bytes_per_launch": int(ab)}
 
@@ -378,7 +408,8 @@ def roofline(job, ms_per_step):
         nl_s = n_s / nroof
         tfl = nfev * fpe / nl_s / (ms_s / n_s * 1e-3) / 1e12
         solve_rec = {"bound": "valu_fp64", "kernel": "k_solve", "achieved": round(tfl, 3), "peak": FP64_VALU_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(tfl / FP64_VALU_PEAK_TFLOPS, 5), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(tfl / FP64_VALU_PEAK_TFLOPS, 5), "traffic": pmc_traffic(args.workload, "k_solve")[0],
+                     "traffic_source": pmc_traffic(args.workload, "k_solve")[1],
                      "avg_launch_ms": round(ms_s / n_s, 4), "launches_per_sweep": nl_s, "energy_evaluations_per_sweep": int(nfev),
                      "flop_per_evaluation": fpe, "flop_per_evaluation_source": "FP64 VALU instructions of one energy evaluation in the built kernel's ISA (fma = 2)",
                      "algorithmic_bytes_per_launch": int(ab_of("k_solve", n_s)),
@@ -481,9 +512,14 @@ def run_rank(args):
         total = args.steps + args.warmup
         if total > MAX_SWEEPS_WITHOUT_REWIND and not args.no_rewind and factory is None:
             job.enable_rewind()
-        elapsed = job.timed(args.steps, args.warmup)
+        # three timed windows of K sweeps over the same states; the record is the MEDIAN window, the others are listed
+        wins = sorted(job.timed(args.steps, args.warmup, windows=args.windows))
+        elapsed = wins[len(wins) // 2]
         ms = 1e3 * elapsed / max(args.steps, 1)
-        rec = {"value": round((T - 1) * args.steps / elapsed, 1), "ms_per_step": round(ms, 4), "poses": T,
+        rec = {"value": round((T - 1) * args.steps / elapsed, 1), "ms_per_step": round(ms, 4),
+               "ms_per_step_windows": {"n": len(wins), "min": round(1e3 * wins[0] / max(args.steps, 1), 4),
+                                       "median": round(ms, 4), "max": round(1e3 * wins[-1] / max(args.steps, 1), 4)},
+               "poses": T,
                "poses_per_gpu": job.blk, "scaling": mode,
                "workload": ("%s: synthetic %d poses / %d landmarks / %d beams, red-black ICM sweep" % (args.workload, T, K, B))
                + ("" if world == 1 else
@@ -500,15 +536,16 @@ def run_rank(args):
     out = {
         "metric": "ICM pose-updates/sec (full sweep)", "value": rec["value"], "unit": "pose-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
+        "ms_per_step_windows": rec["ms_per_step_windows"],
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": rec["workload"], "schedule": "redblack", "poses": rec["poses"], "poses_per_gpu": rec["poses_per_gpu"],
                    "landmarks": K, "beams": B, "kept_beams": st["kept_beams"] if world == 1 else None,
                    "parallelism": "pose-shard x%d" % world,
                    "entry_pipeline": job.eng.entry_path() if hasattr(job.eng, "entry_path") else None,
-                   "segments_pipelined": bool(job.eng.pipeline_used()) if hasattr(job.eng, "pipeline_used") else None,
+                   "fixup_poses": job.eng.fixup_poses() if hasattr(job.eng, "fixup_poses") else None,
                    "state_rewind": ("initial state restored on the device every %d sweeps" % RESET_EVERY) if job.rewind
-                   else "none: %d consecutive sweeps from the initial state" % (args.steps + args.warmup),
-                   "collectives_per_sweep": 0 if not sharded else "1 all-gather of [3L+8] f64 statistics + 1 halo all-gather of 48 B per rank",
+                   else "none inside a timed window: %d consecutive sweeps from the initial state per window" % (args.steps + args.warmup + 1),
+                   "collectives_per_sweep": 0 if not sharded else "1 all-gather of [3L+16] f64 per rank (landmark statistics + the shard's boundary poses); no halo exchange (ghost pose)",
                    "collectives_issued_by": None if not sharded else
                    ("C library (ncclAllGather on the handle's stream)" if args.collectives == "library" and factory is None
                     else "torch.distributed (all_gather_into_tensor)") + ((": " + collectives_note) if collectives_note else "")},
@@ -541,7 +578,7 @@ def run_rank(args):
     if rank == 0 and world == 1 and factory is None and not args.no_extras and args.workload == "S2":
         # BASELINE.json configs[2]: S1 (10k poses / 1k landmarks / 360 beams), 20 consecutive ICM iterations
         j3 = Job(args, "S1", *WORKLOADS["S1"], rank, world, local_rank, False, None)
-        el = j3.timed(20, 2)
+        el = j3.timed(20, 2)[0]
         out["config3"] = {"workload": "S1: synthetic 10000 poses / 1000 landmarks / 360 beams, 20 consecutive red-black sweeps (BASELINE.json configs[2])",
                           "steps": 20, "warmup": 2, "ms_per_step": round(1e3 * el / 20, 4), "value": round((j3.T - 1) * 20 / el, 1),
                           "unit": "pose-updates/s"}
@@ -566,7 +603,7 @@ def main():
     ap.add_argument("--cpu-poses", type=int, default=-1, help="prefix length of the CPU baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the drop-in and config-3 records")
-    ap.add_argument("--pipeline", action="store_true", help="two time segments pipelined over two streams (icm_set_pipeline(h, 1)): A/B comparison")
+    ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps sweeps each over the same states (median reported)")
     ap.add_argument("--no-rewind", action="store_true", help="never rewind the state, however many sweeps")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="N > 1: strong = the workload's sequence split N ways (BASELINE configs[4], the headline); "

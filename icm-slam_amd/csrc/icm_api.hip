@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/icmslam.h"
+#include "../../include/icmslam_tuning.h"
 #include "icm_host.hpp"
 #include "eval_flops.h"
 #include "icm_kernels.hip"
@@ -114,8 +115,9 @@ struct icm_handle {
     DevBuf<double> rec_s, rec_off, ms;   // [3][nrec], [3][nrec], [3][nsuper][L]
     int nchunks = 0, chunk_poses = 64, chunk_group = 1, nsuper = 0;
     DevBuf<int> st_off;      // where each pose's staged entries start (k_assoc_group: packed area or sparse area)
-    int64_t st_sparse0 = 0;  // first entry of the sparse area (behind the packed one)
-    size_t st_stride = 0;    // entries of the staging area: stride of the per-entry prefix arrays
+    StagingLayout stl;       // sizes of the staging area (staging_layout, icm_host.hpp: the one place that computes them)
+    DevBuf<double> pre_x, pre_y;   // per-entry prefixes of the hierarchical path, one element per staging place (stl.prefix_stride)
+    DevBuf<unsigned> pre_n;
     // icm_snapshot_state / icm_restore_state: device copy of the sweep state (poses, map, search structures)
     struct Snapshot {
         DevBuf<double> x, mapx, mapy, counts_new;
@@ -128,9 +130,19 @@ struct icm_handle {
         bool h_map_valid = true, valid = false, dev_map_current = false;
     } snap;
     DevBuf<int> solve_flags;  // fused red-black solve: [nw] completion flags of the odd waves | [nw] deferred marks of the even waves
-    DevBuf<unsigned long long> solve_ndef;   // even waves that deferred to the fix-up launch, over the handle's life
+    DevBuf<unsigned long long> solve_counts;   // over the handle's life: [0] even waves that deferred to the fix-up launch, [1] poses the fix-up solved because a fold-only lane marked them
     int solve_flag_waves = 0;
     int solve_epoch = 0;
+    DevBuf<int> need;         // [nloc + 2]: fold-only solves mark the poses they leave to the fix-up (epoch stamped; slot 0 = ghost pose; [nloc + 1] = need_seen)
+    int fold_mode = -1;       // -1 automatic (fold-only main kernel + fix-up when the weights are isotropic), 0 never, 1 always
+    // ghost pose of a shard (rank > 0): scan, kept beams, staged entries and moments of pose t_begin - 1
+    bool ghost_uploaded = false;
+    int ghost_n = 0;
+    DevBuf<double> gh_ranges, gh_bd, gh_bx, gh_by, gh_s2, gh_sx, gh_sy, gh_rot, gh_m;
+    DevBuf<int> gh_nkept, gh_boff, gh_bk, gh_label, gh_bloc, gh_st_label, gh_misc;   // gh_misc: [0] nent [1] isnew [2] st_off [3..4] plan (zeros) [8..23] flags
+    DevBuf<unsigned short> gh_st_k;
+    hipEvent_t ev_gh0 = nullptr, ev_gh1 = nullptr;
+    bool ghost_pending = false;   // the ghost chain of this sweep is queued on the solve stream (ev_gh1)
     int fused_spin_limit = 1 << 17;   // polls (x ~0.2 us) an even wave waits for its odd neighbours before deferring
     int fuse_colours = 1;    // 1: both colours of an unsharded red-black sweep in one launch (k_solve_m_fused)
     bool ms_clean = false;   // the [superchunk x L] matrix is zero (cleared on the side stream under the solves)
@@ -138,11 +150,14 @@ struct icm_handle {
     bool hier_ok = true;     // cleared by an overflow until the next icm_set_state
     int path_used = 0;       // pipeline of the last sweep: 0 sort-based, 1 hierarchical
     double* stats_all = nullptr;
-    double *stats_send = nullptr, *halo_send = nullptr, *halo_all = nullptr;   // optional (icm_bind_exchange_send)
+    double* stats_send = nullptr;   // optional (icm_bind_exchange_send)
     int rank = 0, world = 1;
     // collectives issued by the library itself (icm_comm_init): RCCL communicator + the exchange buffers it owns
     ncclComm_t comm = nullptr;
-    DevBuf<double> own_stats_all, own_stats_send, own_halo_send, own_halo_all, own_poses;
+    icm_allgather_fn transport = nullptr;   // icm_comm_init_transport: the caller's all-gather instead of RCCL's
+    void* transport_user = nullptr;
+    bool comm_ready = false;
+    DevBuf<double> own_stats_all, own_stats_send, own_poses;
     int64_t comm_blk = 0;
     int64_t E = 0, n_new_loc = 0, lact_raw = 0;
     int lact0 = 0;
@@ -167,15 +182,8 @@ struct icm_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // raw-map download overlapped with the solves
     hipStream_t copy_stream = nullptr;
-    // Pipelined sweeps (unsharded red-black, hierarchical entry pipeline): the sequence is cut at an
-    // even pose into two time segments; the solves of one segment run on solve_stream beside phase
-    // A/B of the other on the main stream.
-    hipStream_t solve_stream = nullptr;
-    hipEvent_t ev_m[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};   // moments ready / solves done, per segment
+    hipStream_t solve_stream = nullptr;   // side stream of a shard's ghost-pose chain (launch_ghost)
     bool rot_valid = false;          // rot[] holds (cos, sin)(theta - pi/2) of the current poses (written by the solves; k_pose_rot otherwise)
-    bool solves_in_flight = false;   // ev_s[] are recorded and the main stream has not joined them yet
-    int pipeline = 0;                // icm_set_pipeline (off by default: measured slower than one stream)
-    bool pipe_ok = true;             // cleared by a table overflow until the next icm_set_state
     // Optimistic sweep (icm_sweep_classic): the whole sweep is queued without the host looking at phase A's counts
     // and overflow flags in the middle; the kernels that would replace state (solves, Mapa.filtrar) look at the
     // flags themselves, the host reads them with the filtrar result and repeats the sweep the careful way if set.
@@ -185,10 +193,7 @@ struct icm_handle {
     bool scan_wanted = true;   // the next queued-whole sweep runs the scan kernels (new-landmark ranks, a fresh reservation plan)
     bool scan_ran = true;      // ... this sweep did
     bool opt_req = false;      // asked for: by icm_sweep_classic for its first attempt, by icm_set_optimistic for the phase calls
-    int pipe_used = 0;               // the last sweep ran pipelined
-    DevBuf<double> x_bak, l3_carry;
     DevBuf<double> rot;   // (cos, sin)(theta - pi/2) per pose of the shard, refreshed at the start of every sweep (k_pose_rot)
-    DevBuf<int> scan_carry;
     hipEvent_t ev_map = nullptr, ev_copied = nullptr;
     bool map_copy_pending = false;
 };
@@ -316,10 +321,9 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = create_solve_stream(&h->solve_stream)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&h->ev_m[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&h->ev_m[1], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&h->ev_s[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&h->ev_s[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->ev_map, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->ev_gh0, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&h->ev_gh1, hipEventDisableTiming)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_i), 64 * sizeof(int), hipHostMallocMapped)) != hipSuccess ||
         (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_i_dev), h->pin_i, 0)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_d), (size_t)(3 * cfg->L + 16 + 64) * sizeof(double))) != hipSuccess) {
@@ -367,22 +371,27 @@ int icm_destroy(icm_handle* h) {
     h->e_key.release();
     h->skey.release();
     h->sort_tmp.release();
-    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release(); h->solve_ndef.release();
+    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release(); h->solve_counts.release(); h->need.release();
+    h->gh_ranges.release(); h->gh_bd.release(); h->gh_bx.release(); h->gh_by.release(); h->gh_s2.release(); h->gh_sx.release(); h->gh_sy.release();
+    h->gh_rot.release(); h->gh_m.release(); h->gh_nkept.release(); h->gh_boff.release(); h->gh_bk.release(); h->gh_label.release(); h->gh_bloc.release();
+    h->gh_st_label.release(); h->gh_misc.release(); h->gh_st_k.release();
+    if (h->ev_gh0) (void)hipEventDestroy(h->ev_gh0);
+    if (h->ev_gh1) (void)hipEventDestroy(h->ev_gh1);
     h->snap.x.release(); h->snap.mapx.release(); h->snap.mapy.release(); h->snap.counts_new.release();
     h->snap.g_cell.release(); h->snap.g_lm.release(); h->snap.g_nb.release(); h->snap.gpar.release();
     if (h->pin_i) (void)hipHostFree(h->pin_i);
     if (h->pin_d) (void)hipHostFree(h->pin_d);
     h->x_rows.release(); h->pack.release();
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
-    h->own_stats_all.release(); h->own_stats_send.release(); h->own_halo_send.release(); h->own_halo_all.release(); h->own_poses.release();
+    h->own_stats_all.release(); h->own_stats_send.release(); h->own_poses.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_map) (void)hipEventDestroy(h->ev_map);
     if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->solve_stream) { (void)hipStreamSynchronize(h->solve_stream); (void)hipStreamDestroy(h->solve_stream); }
-    for (int q = 0; q < 2; ++q) { if (h->ev_m[q]) (void)hipEventDestroy(h->ev_m[q]); if (h->ev_s[q]) (void)hipEventDestroy(h->ev_s[q]); }
-    h->x_bak.release(); h->l3_carry.release(); h->scan_carry.release(); h->rot.release(); h->st_off.release(); h->chunk_pub.release();
+    h->pre_x.release(); h->pre_y.release(); h->pre_n.release();
+    h->rot.release(); h->st_off.release(); h->chunk_pub.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ICM_OK;
@@ -392,7 +401,6 @@ int icm_set_stream(icm_handle* h, void* s) {
     if (!h) return ICM_ERR_ARG;
     (void)hipSetDevice(h->device);
     if (h->solve_stream) (void)hipStreamSynchronize(h->solve_stream);
-    h->solves_in_flight = false;
     (void)hipStreamSynchronize(h->stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = reinterpret_cast<hipStream_t>(s);
@@ -418,16 +426,6 @@ __global__ __launch_bounds__(256) void k_x_poses_to_rows(const double* __restric
     rows[2 * (size_t)T + t] = x[3 * (size_t)t + 2];
 }
 
-// The solves of a pipelined sweep run on solve_stream.  Everything else in this library orders
-// itself on the main stream, so any entry point that reads or replaces the poses first makes the
-// main stream wait for them (the next pipelined sweep waits per segment instead).
-static int join_solves(icm_handle* h) {
-    if (!h->solves_in_flight) return ICM_OK;
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_s[1], 0));   // (ev_s[0] precedes it on the same stream)
-    h->solves_in_flight = false;
-    return ICM_OK;
-}
-
 int icm_upload(icm_handle* h, const double* ranges, const double* odo, const double* u, const double* cosb,
                const double* sinb, int64_t T, int64_t B, int64_t t_begin, int64_t t_end) {
     if (!h) return ICM_ERR_ARG;
@@ -435,7 +433,6 @@ int icm_upload(icm_handle* h, const double* ranges, const double* odo, const dou
     if (T < 2 || B < 1 || t_begin < 0 || t_end > T || t_begin >= t_end) FAIL(h, ICM_ERR_ARG, "icm_upload: bad T/B/shard");
     if (T > (1 << 30) || B > 8192 || (t_end - t_begin) * B > (int64_t)2000000000) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_upload: sequence too large for 32-bit beam indices");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     h->T = T; h->B = B; h->t_begin = t_begin; h->nloc = t_end - t_begin;
     const size_t nr = (size_t)h->nloc * (size_t)B;
     HIPCHK(h, h->ranges.reserve(nr));
@@ -450,9 +447,27 @@ int icm_upload(icm_handle* h, const double* ranges, const double* odo, const dou
     HIPCHK(h, hipMemcpyAsync(h->u.p, u, 2 * (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->uploaded = true;
+    h->ghost_uploaded = false;
+    h->ghost_n = 0;
     h->snap.valid = false;
     h->prefiltered = false;
     h->have_state = false;
+    return ICM_OK;
+}
+
+// The scan of pose t_begin - 1 (the last pose of the shard below): ranks > 0 of a pose-sharded job solve that pose as
+// well (SolveSeg, the ghost pose), so a sharded sweep needs no exchange between its colours.  After icm_upload, before
+// icm_prefilter.
+int icm_upload_ghost_scan(icm_handle* h, const double* ranges_row) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->uploaded || h->prefiltered) FAIL(h, ICM_ERR_ARG, "icm_upload_ghost_scan: between icm_upload and icm_prefilter");
+    if (!ranges_row) FAIL(h, ICM_ERR_ARG, "icm_upload_ghost_scan: null pointer");
+    if (h->t_begin < 2 || (h->t_begin & 1)) FAIL(h, ICM_ERR_ARG, "icm_upload_ghost_scan: a shard with a ghost pose starts at an even pose >= 2");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, h->gh_ranges.reserve((size_t)h->B));
+    HIPCHK(h, hipMemcpyAsync(h->gh_ranges.p, ranges_row, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->ghost_uploaded = true;
     return ICM_OK;
 }
 
@@ -505,19 +520,18 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->rot.reserve(2 * (size_t)nloc));
     TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p)));
     // per-sweep buffers sized by the kept beams
-    // staged entries: the packed area (last sweep's entry count of every pose + kStageSlack) and, behind it, the sparse one
-    h->st_sparse0 = (int64_t)nz + (int64_t)kStageSlack * nloc + kWave;
-    if (h->st_sparse0 + (int64_t)nz + 512 > (int64_t)0x7fffffff) FAIL(h, ICM_ERR_CAPACITY, "too many kept beams for 32-bit entry offsets");
-    const size_t nst = (size_t)h->st_sparse0 + nz + 512;
+    // staged entries (packed area, sparse area behind it) and the per-entry prefixes that live at the same places
+    if (!staging_layout(h->nnz, nloc, h->stl)) FAIL(h, ICM_ERR_CAPACITY, "too many kept beams for 32-bit entry offsets");
+    const size_t nst = (size_t)h->stl.entries, npre = (size_t)h->stl.prefix_stride;
     HIPCHK(h, h->label.reserve(nz)); HIPCHK(h, h->bloc.reserve(nz)); HIPCHK(h, h->st_label.reserve(nst));
     HIPCHK(h, h->st_k.reserve(nst)); HIPCHK(h, h->st_sx.reserve(nst)); HIPCHK(h, h->st_sy.reserve(nst));
     HIPCHK(h, h->st_off.reserve((size_t)nloc + 1));
-    h->st_stride = nst + kWave;
+    HIPCHK(h, h->pre_x.reserve(npre)); HIPCHK(h, h->pre_y.reserve(npre)); HIPCHK(h, h->pre_n.reserve(npre));
     HIPCHK(h, h->btx.reserve(nz)); HIPCHK(h, h->bty.reserve(nz));
+    // sort-based pipeline: compact per-entry records (at most one entry per kept beam)
     HIPCHK(h, h->e_key.reserve(nz)); HIPCHK(h, h->skey.reserve(nz)); HIPCHK(h, h->e_val.reserve(nz + kWave));
     HIPCHK(h, h->sval.reserve(nz)); HIPCHK(h, h->e_k.reserve(nz)); HIPCHK(h, h->e_b.reserve(nz));
-    // (e_w also holds the three per-entry prefix arrays of the hierarchical path: one element per staging place)
-    HIPCHK(h, h->e_w.reserve(std::max<size_t>(nz + kWave, (3 * h->st_stride * sizeof(double) + sizeof(EntW) - 1) / sizeof(EntW) + kWave)));
+    HIPCHK(h, h->e_w.reserve(nz + kWave));
     HIPCHK(h, h->e_wr.reserve(nz)); HIPCHK(h, h->tgt.reserve(nz));
     HIPCHK(h, h->scan_tot.reserve(2 * ((size_t)nloc / kScanTile + 2)));
     HIPCHK(h, h->nent.reserve((size_t)nloc + 1)); HIPCHK(h, h->isnew.reserve((size_t)nloc + 1));
@@ -549,6 +563,30 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         }
         HIPCHK(h, h->ms.reserve(3 * (size_t)h->nsuper * L));
         h->ms_clean = false;
+    }
+    HIPCHK(h, h->need.reserve((size_t)nloc + 2));
+    HIPCHK(h, hipMemsetAsync(h->need.p, 0, ((size_t)nloc + 2) * sizeof(int), h->stream));   // (epochs start at 1)
+    h->solve_epoch = 0;
+    h->solve_flag_waves = 0;   // (flags are cleared with the epoch: launch_fused_solve)
+    h->ghost_n = 0;
+    if (h->ghost_uploaded) {
+        // filtrar_z of the ghost scan (pose t_begin - 1) into the ghost's own arrays, and room for its staged entries:
+        // a one-pose k_assoc_group with an all-zero reservation plan stages them at sparse0 = kWave
+        const size_t Bz = (size_t)B, gst = (size_t)kWave + Bz + 512;
+        HIPCHK(h, h->gh_nkept.reserve(2)); HIPCHK(h, h->gh_boff.reserve(2)); HIPCHK(h, h->gh_bk.reserve(Bz));
+        HIPCHK(h, h->gh_bd.reserve(Bz)); HIPCHK(h, h->gh_bx.reserve(Bz)); HIPCHK(h, h->gh_by.reserve(Bz)); HIPCHK(h, h->gh_s2.reserve(3));
+        HIPCHK(h, h->gh_label.reserve(Bz)); HIPCHK(h, h->gh_bloc.reserve(Bz));
+        HIPCHK(h, h->gh_st_label.reserve(gst)); HIPCHK(h, h->gh_st_k.reserve(gst)); HIPCHK(h, h->gh_sx.reserve(gst)); HIPCHK(h, h->gh_sy.reserve(gst));
+        HIPCHK(h, h->gh_misc.reserve(32)); HIPCHK(h, h->gh_rot.reserve(2)); HIPCHK(h, h->gh_m.reserve(17));
+        HIPCHK(h, hipMemsetAsync(h->gh_misc.p, 0, 32 * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->gh_m.p, 0, 17 * sizeof(double), h->stream));
+        k_prefilter<false><<<1, kBlock, lds, h->stream>>>(h->gh_ranges.p, h->cosb.p, h->sinb.p, 1, B, h->cfg.rango_laser_max, h->cfg.dist_thr, h->gh_nkept.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->gh_nkept.p, h->gh_boff.p, 1);
+        k_prefilter<true><<<1, kBlock, lds, h->stream>>>(h->gh_ranges.p, h->cosb.p, h->sinb.p, 1, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->gh_boff.p, h->gh_bk.p, h->gh_bd.p, h->gh_bx.p, h->gh_by.p, h->gh_s2.p);
+        int gb[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(gb, h->gh_boff.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->ghost_n = gb[1];
     }
     size_t tmp_bytes = 0;
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, nz, 0, 32, h->stream));
@@ -615,7 +653,6 @@ static int set_state_impl(icm_handle* h, const double* x, const double* x0, cons
     if (lact_in < K) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_set_state: landmarks_actuales < columns of mapa_viejo is not supported");
     if (lact_in > h->cfg.L) FAIL(h, ICM_ERR_INDEX, "icm_set_state: landmarks_actuales > L");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     const size_t T = (size_t)h->T;
     if (!h->x_external) {  // (re)size with the sequence: a handle may be re-used for a longer one
         HIPCHK(h, h->x_own.reserve(3 * T));
@@ -645,7 +682,6 @@ static int set_state_impl(icm_handle* h, const double* x, const double* x0, cons
     h->rot_valid = false;
     h->scan_wanted = true;
     h->hier_ok = true;
-    h->pipe_ok = true;
     if (wait_host) HIPCHK(h, hipStreamSynchronize(h->stream));
     return ICM_OK;
 }
@@ -654,7 +690,14 @@ int icm_set_state(icm_handle* h, const double* x, const double* x0, const double
     return set_state_impl(h, x, x0, map_in, K, lact_in, true);
 }
 
-int64_t icm_stats_stride(const icm_handle* h) { return h ? 3 * h->cfg.L + 8 : 0; }
+// A rank's statistics message: [sum x (L) | sum y (L) | n (L) | header (kStatsHeader)].  Header: [0] landmarks the rank
+// created, [1] 0 = fine, 1 = one of its tables overflowed (a sweep queued whole: every rank then leaves its state alone),
+// >= 2 = the rank failed in the careful form with error code -([1]) ... see sweep_sharded_once, [2..4] its first pose,
+// [5..7] its last pose, [8..10] its last pose but one -- values at the START of the sweep, i.e. the previous sweep's
+// results: what the neighbours need as OLD values (the rank above: the two poses around its ghost solve; the rank
+// below: the pose after its last odd pose).  One message, one collective per sweep.
+constexpr int kStatsHeader = 16;
+int64_t icm_stats_stride(const icm_handle* h) { return h ? 3 * h->cfg.L + kStatsHeader : 0; }
 
 int icm_bind_exchange(icm_handle* h, void* stats_all_dev, int rank, int world) {
     if (!h) return ICM_ERR_ARG;
@@ -666,53 +709,22 @@ int icm_bind_exchange(icm_handle* h, void* stats_all_dev, int rank, int world) {
     return ICM_OK;
 }
 
-int icm_bind_exchange_send(icm_handle* h, void* stats_send_dev, void* halo_send_dev, void* halo_all_dev) {
+int icm_bind_exchange_send(icm_handle* h, void* stats_send_dev) {
     if (!h) return ICM_ERR_ARG;
-    if ((halo_send_dev == nullptr) != (halo_all_dev == nullptr)) FAIL(h, ICM_ERR_ARG, "icm_bind_exchange_send: halo_send and halo_all go together");
     h->stats_send = reinterpret_cast<double*>(stats_send_dev);
-    h->halo_send = reinterpret_cast<double*>(halo_send_dev);
-    h->halo_all = reinterpret_cast<double*>(halo_all_dev);
     return ICM_OK;
 }
 
-// first / last pose of the shard, clamped into the sequence (an empty shard sends pose values nobody reads)
+// first / last / last-but-one pose of the shard, clamped into the sequence (values nobody reads where they do not exist)
 static int edge_first(const icm_handle* h) { return (int)std::min<int64_t>(h->t_begin, std::max<int64_t>(h->T - 1, 0)); }
 static int edge_last(const icm_handle* h) {
     return (int)std::min<int64_t>(std::max<int64_t>(h->t_begin + h->nloc - 1, 0), std::max<int64_t>(h->T - 1, 0));
 }
+static int edge_last2(const icm_handle* h) { return std::max(edge_last(h) - 1, 0); }
 
 // this rank's slot of the landmark statistics: the send buffer if one is bound
 static double* stats_slot(icm_handle* h) {
     return h->stats_send ? h->stats_send : h->stats_all + (size_t)h->rank * (size_t)icm_stats_stride(h);
-}
-
-__global__ void k_halo_pack(const double* __restrict__ x, int first, int last, double* __restrict__ send) {
-    const int i = threadIdx.x;
-    if (i < 3) send[i] = x[3 * (size_t)first + i];
-    else if (i < 6) send[i] = x[3 * (size_t)last + (i - 3)];
-}
-
-__global__ void k_halo_unpack(double* __restrict__ x, const double* __restrict__ all, int rank, int below, int above) {
-    const int i = threadIdx.x;  // below / above: pose index to fill, -1 = none
-    if (i < 3) {
-        if (below >= 0) x[3 * (size_t)below + i] = all[6 * (size_t)(rank - 1) + 3 + i];
-    } else if (i < 6) {
-        if (above >= 0) x[3 * (size_t)above + (i - 3)] = all[6 * (size_t)(rank + 1) + (i - 3)];
-    }
-}
-
-int icm_halo_unpack(icm_handle* h) {
-    if (!h) return ICM_ERR_ARG;
-    if (!h->halo_all) FAIL(h, ICM_ERR_ARG, "icm_halo_unpack: no halo buffers bound (icm_bind_exchange_send)");
-    if (!h->uploaded || h->nloc == 0) return ICM_OK;
-    HIPCHK(h, hipSetDevice(h->device));
-    const int a = (int)h->t_begin, b = (int)(h->t_begin + h->nloc);
-    const int below = (a > 0 && h->rank > 0) ? a - 1 : -1;
-    const int above = (b < (int)h->T && h->rank + 1 < h->world) ? b : -1;
-    if (below < 0 && above < 0) return ICM_OK;
-    k_halo_unpack<<<1, 8, 0, h->stream>>>(h->x, h->halo_all, h->rank, below, above);
-    HIPCHK(h, hipGetLastError());
-    return ICM_OK;
 }
 
 int icm_bind_pose_buffer(icm_handle* h, void* x_dev) {
@@ -734,29 +746,42 @@ void* icm_pose_buffer(icm_handle* h) {
     return h->x;
 }
 
-// header of a rank's statistics message: [0] new landmarks, [1] flags, [2..4] first pose of the
-// shard, [5..7] last pose -- the boundary poses ride along, so the halo exchange that would
-// precede the next odd half sweep needs no collective of its own
+// Header of a rank's statistics message (layout: icm_stats_stride above).
 // n_new_dev / flags_dev (nullable): the values on the device, for a sweep queued without a host look at them
 // ([1] = 1 when one of this rank's tables overflowed or its labels exceed L: every rank then leaves state alone).
 __global__ void k_set_header(double* stats, int L, double n_new, double flags, const double* __restrict__ x, int first, int last,
-                             const int* __restrict__ n_new_dev = nullptr, const int* __restrict__ flags_dev = nullptr) {
+                             int last2, const int* __restrict__ n_new_dev = nullptr, const int* __restrict__ flags_dev = nullptr) {
     double* hd = stats + 3 * (size_t)L;
     hd[0] = n_new_dev ? (double)*n_new_dev : n_new;
     hd[1] = flags_dev ? ((flags_dev[0] | flags_dev[1] | flags_dev[2]) ? 1.0 : 0.0) : flags;
     for (int i = 0; i < 3; ++i) {
         hd[2 + i] = x[3 * (size_t)first + i];
         hd[5 + i] = x[3 * (size_t)last + i];
+        hd[8 + i] = x[3 * (size_t)last2 + i];
     }
 }
 
+// The neighbours' boundary poses out of their headers into this rank's copy of the pose array: below = the pose index
+// t_begin - 1 (the ghost pose; its predecessor t_begin - 2 comes with it, and the ghost's rotation pair is formed from
+// its owner's value), above = the pose index t_begin + nloc; -1 = none.
 __global__ void k_halo_from_headers(double* __restrict__ x, const double* __restrict__ stats_all, int stride, int L, int rank,
-                                    int below, int above) {
+                                    int below, int above, double* __restrict__ ghost_rot) {
     const int i = threadIdx.x;
     if (i < 3) {
-        if (below >= 0) x[3 * (size_t)below + i] = stats_all[(size_t)(rank - 1) * stride + 3 * (size_t)L + 5 + i];
+        if (below >= 0) {
+            const double* hd = stats_all + (size_t)(rank - 1) * stride + 3 * (size_t)L;
+            x[3 * (size_t)below + i] = hd[5 + i];
+            if (below >= 1) x[3 * (size_t)(below - 1) + i] = hd[8 + i];
+        }
     } else if (i < 6) {
         if (above >= 0) x[3 * (size_t)above + (i - 3)] = stats_all[(size_t)(rank + 1) * stride + 3 * (size_t)L + 2 + (i - 3)];
+    } else if (i == 6) {
+        if (below >= 0 && ghost_rot) {
+            double ct, st;
+            pose_rot(stats_all[(size_t)(rank - 1) * stride + 3 * (size_t)L + 7], ct, st);
+            ghost_rot[0] = ct;
+            ghost_rot[1] = st;
+        }
     }
 }
 
@@ -842,7 +867,6 @@ int icm_sweep_local(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_local: no state (icm_set_state)");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     h->optimistic = h->opt_req && optimistic_applies(h);
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     // pose 0 without kept beams: the reference returns its inputs untouched
@@ -867,7 +891,7 @@ int icm_sweep_local(icm_handle* h) {
     TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS, (PRE || DBG) ? 1 : ICM_ASSOC_PPW>                         \
         <<<nblocks_waves((nloc + ((PRE || DBG) ? 1 : ICM_ASSOC_PPW) - 1) / ((PRE || DBG) ? 1 : ICM_ASSOC_PPW)), kBlock, 0, h->stream>>>( \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
-        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->st_sparse0)))
+        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->stl.sparse0)))
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
     if (!h->rot_valid) {   // (the poses came from the host, a snapshot or a solve form that does not keep the table)
         TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p)));
@@ -887,8 +911,6 @@ int icm_sweep_local(icm_handle* h) {
     const bool run_scan = !(h->optimistic && hier) || h->scan_wanted;
     h->scan_ran = run_scan;
     const int nrec = h->nchunks * kT1;
-    double* const pre = reinterpret_cast<double*>(h->e_w.p);   // [3][nnz] (the sort-based path's record buffer)
-    const size_t nzs = h->st_stride;
     double* const ms = h->ms.p;
     const size_t msn = (size_t)h->nsuper * (size_t)L;
     for (;;) {
@@ -906,7 +928,7 @@ int icm_sweep_local(icm_handle* h) {
 #define CHUNK_L1(CH)                                                                                                   \
     TIMED(h, KID_CHUNK_L1, (k_chunk_l1<CH><<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(                          \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->st_off.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0, \
-        h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs, reinterpret_cast<unsigned*>(pre + 2 * nzs),        \
+        h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pre_x.p, h->pre_y.p, h->pre_n.p,                                   \
         h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, 0,                           \
         run_scan ? nullptr : h->flags.p + 8, h->isnew.p, h->chunk_pub.p, h->scan_epoch, 1 << 16)))
             if (h->chunk_poses == 64) CHUNK_L1(64); else if (h->chunk_poses == 32) CHUNK_L1(32); else CHUNK_L1(16);
@@ -940,7 +962,7 @@ int icm_sweep_local(icm_handle* h) {
     if (h->optimistic && hier) {
         h->path_used = 1;
         if (h->world > 1)
-            k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, 0.0, 0.0, h->x, edge_first(h), edge_last(h), run_scan ? h->new_rank.p + nloc : h->flags.p + 9, h->flags.p);
+            k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, 0.0, 0.0, h->x, edge_first(h), edge_last(h), edge_last2(h), run_scan ? h->new_rank.p + nloc : h->flags.p + 9, h->flags.p);
         HIPCHK(h, hipGetLastError());
         return ICM_OK;
     }
@@ -958,7 +980,7 @@ int icm_sweep_local(icm_handle* h) {
     }
     h->path_used = hier ? 1 : 0;
     if (hier) {
-        if (h->world > 1) k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, (double)h->n_new_loc, 0.0, h->x, edge_first(h), edge_last(h));
+        if (h->world > 1) k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, (double)h->n_new_loc, 0.0, h->x, edge_first(h), edge_last(h), edge_last2(h));
         HIPCHK(h, hipGetLastError());
         return ICM_OK;
     }
@@ -972,9 +994,71 @@ int icm_sweep_local(icm_handle* h) {
     if (h->world > 1) {
         double* stats_mine = stats_slot(h);
         TIMED(h, KID_LM_TOTALS, (k_lm_scan<true><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, nullptr, nullptr, nullptr, nullptr, stats_mine, nullptr, nullptr)));
-        k_set_header<<<1, 1, 0, h->stream>>>(stats_mine, L, (double)h->n_new_loc, 0.0, h->x, edge_first(h), edge_last(h));
+        k_set_header<<<1, 1, 0, h->stream>>>(stats_mine, L, (double)h->n_new_loc, 0.0, h->x, edge_first(h), edge_last(h), edge_last2(h));
     }
     HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
+// The ghost pose of a shard (the last pose of the rank below, solved here too: SolveSeg): its kept beams associated and
+// grouped against mapa_viejo with its owner's previous-sweep value, then its moments against the running means through
+// that pose = the totals of all lower ranks (k_stats_prefix has just left them in off_*).  Two one-wave launches on the
+// solve stream, beside k_rec_push / k_pose_moments_h; the solve launch waits for them (ev_gh1).
+static int launch_ghost(icm_handle* h) {
+    if (h->ghost_n <= 0) return ICM_OK;   // (a ghost scan without kept beams: the no-beam branch of the solve needs no moments)
+    const int L = (int)h->cfg.L;
+    hipStream_t gs = h->timing ? h->stream : h->solve_stream;
+    if (!h->timing) {
+        HIPCHK(h, hipEventRecord(h->ev_gh0, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(gs, h->ev_gh0, 0));
+    }
+    int* gm = h->gh_misc.p;   // [0] nent [1] isnew [2] st_off [3..4] reservation plan (zeros) [8..23] the ghost launch's flags
+    HIPCHK(h, hipMemsetAsync(gm + 8, 0, 16 * sizeof(int), gs));
+    k_assoc_group<false, false, 256><<<1, kBlock, 0, gs>>>(h->x, h->x0.p, (int)h->t_begin - 1, 1, h->gh_boff.p, h->gh_bx.p, h->gh_by.p,
+        GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p}, h->cfg.dist_thr, h->thr2, h->gh_label.p, h->gh_bloc.p, h->gh_st_label.p,
+        h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p, gm, gm + 1, gm + 8, h->gh_rot.p, h->ghost_n, gm + 2, gm + 3, 0, kWave);
+    k_ghost_moments<<<1, kWave, 0, gs>>>(h->x, (int)h->t_begin - 1, gm, gm + 2, h->gh_st_label.p, h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p,
+        h->gh_s2.p, h->gh_rot.p, h->off_sx.p, h->off_sy.p, h->off_n.p,
+        h->stats_all + (size_t)(h->rank - 1) * (size_t)icm_stats_stride(h), L, h->lact0, h->gh_m.p, gm + 8, h->flags.p);
+    HIPCHK(h, hipGetLastError());
+    if (!h->timing) {   // (icm_sweep_solve makes the main stream wait for it in front of the solve launch)
+        HIPCHK(h, hipEventRecord(h->ev_gh1, gs));
+        h->ghost_pending = true;
+    }
+    return ICM_OK;
+}
+
+// Callers that issue the collective themselves (icm_bind_exchange): a rank whose icm_sweep_local failed in the careful
+// form must still send its message -- with the error code in the header ([1] = 1 - code >= 2) -- so that the other ranks
+// do not wait for it; after the exchange every rank looks at every header (icm_failed_rank) and fails together.
+int icm_mark_failed(icm_handle* h, int code) {
+    if (!h) return ICM_ERR_ARG;
+    if (code >= 0) FAIL(h, ICM_ERR_ARG, "icm_mark_failed: an error code is negative");
+    if (!h->have_state || (h->world > 1 && !h->stats_all)) FAIL(h, ICM_ERR_ARG, "icm_mark_failed: no state / no exchange buffer");
+    HIPCHK(h, hipSetDevice(h->device));
+    k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), (int)h->cfg.L, 0.0, (double)(1 - code), h->x, edge_first(h), edge_last(h), edge_last2(h));
+    HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
+// After the exchange, careful form: the first rank whose header carries an error code (-1: none), and that code.
+int icm_failed_rank(icm_handle* h, int* rank_out, int* code_out) {
+    if (!h || !rank_out || !code_out) return ICM_ERR_ARG;
+    *rank_out = -1;
+    *code_out = 0;
+    if (h->world <= 1 || !h->stats_all) return ICM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t stride = (size_t)icm_stats_stride(h), L = (size_t)h->cfg.L;
+    std::vector<double> hd((size_t)h->world);
+    for (int r = 0; r < h->world; ++r)
+        HIPCHK(h, hipMemcpyAsync(&hd[(size_t)r], h->stats_all + (size_t)r * stride + 3 * L + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < h->world; ++r)
+        if (hd[(size_t)r] >= 2.0) {
+            *rank_out = r;
+            *code_out = 1 - (int)hd[(size_t)r];
+            break;
+        }
     return ICM_OK;
 }
 
@@ -986,32 +1070,39 @@ int icm_sweep_targets(icm_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     const int nlab = h->lact0 + (int)h->n_new_loc;
-    if (h->world > 1 && h->halo_all) {
-        // the neighbours' boundary poses came with their statistics
+    const bool ghost = h->world > 1 && h->rank > 0;
+    if (h->world > 1) {
+        // the neighbours' boundary poses (previous-sweep values) came with their statistics
         const int a = (int)h->t_begin, b = (int)(h->t_begin + h->nloc);
-        const int below = (a > 0 && h->rank > 0) ? a - 1 : -1;
+        const int below = ghost ? a - 1 : -1;
         const int above = (b < (int)h->T && h->rank + 1 < h->world) ? b : -1;
         if (below >= 0 || above >= 0)
-            k_halo_from_headers<<<1, 8, 0, h->stream>>>(h->x, h->stats_all, (int)icm_stats_stride(h), L, h->rank, below, above);
+            k_halo_from_headers<<<1, 8, 0, h->stream>>>(h->x, h->stats_all, (int)icm_stats_stride(h), L, h->rank, below, above, ghost ? h->gh_rot.p : nullptr);
     }
     if (h->path_used == 1) {
         const int nrec = h->nchunks * kT1;
         const size_t msn = (size_t)h->nsuper * (size_t)L;
-        const size_t nzs = h->st_stride;
-        const double* pre = reinterpret_cast<const double*>(h->e_w.p);
         double* ro = h->rec_off.p;
         if (h->world > 1)
             TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p, h->optimistic ? h->flags.p : nullptr)));
+        if (ghost) {
+            int rcg = launch_ghost(h);
+            if (rcg) return rcg;
+        }
         TIMED(h, KID_REC_PUSH, (k_rec_push<<<nblocks_threads(nrec), kBlock, 0, h->stream>>>(
             nrec, h->chunk_group, L, h->rec_label.p, h->ms.p, h->ms.p + msn, h->ms.p + 2 * msn,
             h->world > 1 ? h->off_sx.p : nullptr, h->world > 1 ? h->off_sy.p : nullptr, h->world > 1 ? h->off_n.p : nullptr,
             ro, ro + nrec, ro + 2 * (size_t)nrec)));
         TIMED(h, KID_POSE_MOMENTS, (k_pose_moments_h<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(
             h->x, h->x0.p, (int)h->t_begin, nloc, h->st_off.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p,
-            pre, pre + nzs, reinterpret_cast<const unsigned*>(pre + 2 * nzs), h->chunk_poses,
+            h->pre_x.p, h->pre_y.p, h->pre_n.p, h->chunk_poses,
             ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr, 0, -1, h->rot.p)));
     } else if (h->world > 1) {
         TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
+        if (ghost) {
+            int rcg = launch_ghost(h);
+            if (rcg) return rcg;
+        }
         TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, h->off_sx.p, h->off_sy.p, h->off_n.p, h->tgt.p, nullptr, nullptr, nullptr)));
     } else {
         TIMED(h, KID_LM_SCAN, (k_lm_scan<false><<<nblocks_waves(L), kBlock, 0, h->stream>>>(nlab, L, h->lm_off.p, h->sval.p, h->e_w.p, nullptr, nullptr, nullptr, h->tgt.p, nullptr, h->y_raw.p, h->cnt_raw.p)));
@@ -1050,41 +1141,7 @@ int icm_sweep_targets(icm_handle* h) {
     return ICM_OK;
 }
 
-// Both colours of the poses [g.t0, g.t1) in one launch (k_solve_m_fused) plus the fix-up launch for
-// even waves that deferred, on stream st.
-static int launch_fused_solve(icm_handle* h, const SolveArgs& a, SolveSeg g, hipStream_t st) {
-    const int64_t npc = (g.t1 - g.t0) / 2 + 1;   // poses per colour (upper bound)
-    const bool quad = h->solve_quad == 1;   // (automatic = one lane per pose: see icm_sweep_solve)
-    const int ppw = quad ? kWave / 4 : kWave;   // (fewer poses per lane-form wave was measured: 32 at S1 -8 %, 2 at 600 poses +38 %: not adopted)
-    const int nwv = (int)((npc + ppw - 1) / ppw);
-    if (h->solve_flag_waves < nwv) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));   // (re-allocation: nothing may still be polling the old flags)
-        if (h->solve_stream) HIPCHK(h, hipStreamSynchronize(h->solve_stream));
-        HIPCHK(h, h->solve_flags.reserve(2 * (size_t)nwv));
-        HIPCHK(h, h->solve_ndef.reserve(1));
-        HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, 2 * (size_t)nwv * sizeof(int), st));
-        HIPCHK(h, hipMemsetAsync(h->solve_ndef.p, 0, sizeof(unsigned long long), st));
-        h->solve_flag_waves = nwv;
-        h->solve_epoch = 0;
-    }
-    ++h->solve_epoch;   // (flags hold the epoch of the launch that set them: no reset between launches)
-    int* const deferred = h->solve_flags.p + h->solve_flag_waves;
-    if (quad) {
-        TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nblocks_waves(2 * nwv), kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->solve_epoch, h->fused_spin_limit, deferred)));
-        TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_deferred<true><<<nblocks_waves(nwv), kBlock, 0, st>>>(a, g, nwv, deferred, h->solve_ndef.p)));
-    } else {
-        TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nblocks_waves(2 * nwv), kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->solve_epoch, h->fused_spin_limit, deferred)));
-        TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_deferred<false><<<nblocks_waves(nwv), kBlock, 0, st>>>(a, g, nwv, deferred, h->solve_ndef.p)));
-    }
-    HIPCHK(h, hipGetLastError());
-    return ICM_OK;
-}
-
-int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
-    if (!h) return ICM_ERR_ARG;
-    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: no state");
-    if (h->scan0_empty) return ICM_OK;
-    HIPCHK(h, hipSetDevice(h->device));
+static SolveArgs solve_args(icm_handle* h) {
     SolveArgs a;
     a.x = h->x; a.x0 = h->x0.p; a.odo = h->odo.p; a.u = h->u.p;
     a.T = (int)h->T; a.t_begin = (int)h->t_begin; a.nloc = (int)h->nloc;
@@ -1094,6 +1151,73 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     a.tgt = h->tgt.p; a.pose_c = h->pose_c.p; a.pose_m = h->pose_m.p;
     a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
     a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
+    a.diag = nullptr;
+    a.rot = h->rot.p;
+    a.need = h->need.p;
+    a.need_seen = h->need.p + h->nloc + 1;
+    a.epoch = 0;
+    a.ghost_n = h->ghost_n;
+    a.ghost_m = h->gh_m.p;
+    return a;
+}
+
+// The segment of the pose sequence this handle solves: the whole sequence, or -- a shard of a multi-rank job --
+// its block plus the ghost pose in front (SolveSeg: t0 = t_begin - 2).
+static SolveSeg shard_segment(const icm_handle* h, const int* abort) {
+    const bool ghost = h->world > 1 && h->rank > 0;
+    return SolveSeg{ghost ? (int)h->t_begin - 2 : (int)h->t_begin, (int)(h->t_begin + h->nloc), 0, abort};
+}
+
+// Both colours of the poses [g.t0, g.t1) in one launch (k_solve_m_fused) plus the fix-up launches behind it (poses a
+// fold-only lane left to the complete energy; even waves that deferred), on stream st.
+static int launch_fused_solve(icm_handle* h, SolveArgs a, SolveSeg g, hipStream_t st) {
+    const int64_t npc = (g.t1 - g.t0) / 2 + 1;   // poses per colour (upper bound)
+    const bool quad = h->solve_quad == 1;   // (automatic = one lane per pose: see icm_sweep_solve)
+    const int ppw = quad ? kWave / 4 : kWave;   // (fewer poses per lane-form wave was measured: 32 at S1 -8 %, 2 at 600 poses +38 %: not adopted)
+    const int nwv = (int)((npc + ppw - 1) / ppw);
+    if (h->solve_flag_waves < nwv) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // (re-allocation: nothing may still be polling the old flags)
+        if (h->solve_stream) HIPCHK(h, hipStreamSynchronize(h->solve_stream));
+        HIPCHK(h, h->solve_flags.reserve(2 * (size_t)nwv));
+        HIPCHK(h, h->solve_counts.reserve(2));
+        HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, 2 * (size_t)nwv * sizeof(int), st));
+        HIPCHK(h, hipMemsetAsync(h->solve_counts.p, 0, 2 * sizeof(unsigned long long), st));
+        HIPCHK(h, hipMemsetAsync(h->need.p, 0, ((size_t)h->nloc + 2) * sizeof(int), st));
+        h->solve_flag_waves = nwv;
+        h->solve_epoch = 0;
+    }
+    a.epoch = ++h->solve_epoch;   // (flags and marks hold the epoch of the launch that set them: no reset between launches)
+    int* const deferred = h->solve_flags.p + h->solve_flag_waves;
+    // Fold-only main kernel (thirteen coefficients per pose, no scratch) whenever the folded form can hold at all, i.e.
+    // with isotropic weights; the complete energy in the main kernel otherwise (every pose would go to the fix-up).
+    const bool iso = h->cfg.Q[0] == h->cfg.Q[1] && h->cfg.R[0] == h->cfg.R[1];
+    const bool fold = h->fold_mode < 0 ? iso : h->fold_mode == 1;
+    const int nb2 = nblocks_waves(2 * nwv), nb1 = nblocks_waves(nwv);
+#define FUSED(Q, F) TIMED(h, KID_SOLVE, (k_solve_m_fused<Q, F><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred)))
+#define FIX(Q, EVEN) TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_fix<Q><<<nb1, kBlock, 0, st>>>(a, g, nwv, EVEN, deferred, h->solve_counts.p)))
+    if (quad) {
+        if (fold) { FUSED(true, true); FIX(true, 0); } else FUSED(true, false);
+        FIX(true, 1);
+    } else {
+        if (fold) { FUSED(false, true); FIX(false, 0); } else FUSED(false, false);
+        FIX(false, 1);
+    }
+#undef FUSED
+#undef FIX
+    HIPCHK(h, hipGetLastError());
+    return ICM_OK;
+}
+
+int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: no state");
+    if (h->scan0_empty) return ICM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->ghost_pending) {   // the ghost pose's moments (launch_ghost, solve stream)
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gh1, 0));
+        h->ghost_pending = false;
+    }
+    SolveArgs a = solve_args(h);
     if (h->debug) {
         const bool fresh = h->diag.cap < 3 * (size_t)h->T;
         HIPCHK(h, h->diag.reserve(3 * (size_t)h->T));
@@ -1106,40 +1230,42 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     // the next sweep needs no k_pose_rot launch
     a.rot = h->form == 0 ? h->rot.p : nullptr;
     if (h->form != 0) h->rot_valid = false;   // (the cross-check forms do not keep it)
+    const int* abort = h->optimistic ? h->flags.p : nullptr;
+    if (h->world > 1 && h->form != 0)
+        FAIL(h, ICM_ERR_UNSUPPORTED, "the per-beam / per-entry cross-check forms of the energy are single-rank only (a shard's ghost pose is solved in moment form)");
+    if (h->world > 1 && h->rank > 0 && ((h->t_begin & 1) || h->t_begin < 2 || !h->ghost_uploaded))
+        FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: a shard of a multi-rank job starts at an even pose and needs the scan of the pose in front of it (icm_upload_ghost_scan)");
     if (schedule == ICM_SCHEDULE_SEQUENTIAL) {
         if (h->world != 1) FAIL(h, ICM_ERR_UNSUPPORTED, "the sequential (reference-order) schedule is one dependent chain and cannot be sharded");
         if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
         else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_sequential<false><<<1, kWave, 0, h->stream>>>(a)));
         else TIMED(h, KID_SOLVE, (k_solve_m_sequential<<<1, kWave, 0, h->stream>>>(a)));
-    } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->world == 1 && h->t_begin == 0 && h->form == 0 && h->fuse_colours) {
-        // both colours of an unsharded sweep in one launch, even waves chase the odd ones
-        int rc = launch_fused_solve(h, a, SolveSeg{0, (int)h->nloc, 0, h->optimistic ? h->flags.p : nullptr}, h->stream);
+    } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->form == 0 && h->fuse_colours) {
+        // both colours in one launch, even waves chase the odd ones (a shard: its ghost pose is the first odd pose)
+        int rc = launch_fused_solve(h, a, shard_segment(h, abort), h->stream);
         if (rc) return rc;
     } else if (schedule == ICM_SCHEDULE_REDBLACK) {
-        const int nw = (int)(h->nloc / 2 + 1);
+        const SolveSeg g = shard_segment(h, abort);
+        const int nw = (g.t1 - g.t0) / 2 + 1;
         for (int col = 1; col >= 0; --col) {
             if (!(colour == col || colour < 0)) continue;
             if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_colour<true><<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, col)));
             else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_colour<false><<<nblocks_waves(nw), kBlock, 0, h->stream>>>(a, col)));
             else {
                 // Throughput form: one lane per pose (64 poses per wave).  Latency form: one DPP quad
-                // per pose evaluating the four candidate points of an iteration at once -- used when
-                // a colour has too few poses to fill the chip's 1024 SIMDs even at 16 poses per wave
-                // (small sequences, small shards), where only the length of the serial chain counts.
+                // per pose evaluating the four candidate points of an iteration at once.
                 // With the folded energy an evaluation is a sixth of an iteration's instructions, so the quad's
                 // one-evaluation iteration no longer pays for its broadcasts: the lane form is faster at every
                 // size measured (S1: 0.122 against 0.157 ms, 600 poses: 0.099 against 0.115) and is the
                 // automatic choice; the quad form stays selectable (icm_set_solve_lanes) and bit-identical.
                 const bool quad = h->solve_quad == 1;
-                if (quad) TIMED(h, KID_SOLVE, (k_solve_mq_colour<<<nblocks_threads((int64_t)nw * 4), kBlock, 0, h->stream>>>(a, col, h->optimistic ? h->flags.p : nullptr)));
-                else TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_waves((nw + kWave - 1) / kWave), kBlock, 0, h->stream>>>(a, col, h->optimistic ? h->flags.p : nullptr)));
+                if (quad) TIMED(h, KID_SOLVE, (k_solve_mq_colour<<<nblocks_threads((int64_t)nw * 4), kBlock, 0, h->stream>>>(a, g, col)));
+                else TIMED(h, KID_SOLVE, (k_solve_m_colour<<<nblocks_waves((nw + kWave - 1) / kWave), kBlock, 0, h->stream>>>(a, g, col)));
             }
         }
     } else {
         FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: unknown schedule");
     }
-    if (h->halo_send && h->nloc > 0)
-        k_halo_pack<<<1, 8, 0, h->stream>>>(h->x, edge_first(h), edge_last(h), h->halo_send);
     HIPCHK(h, hipGetLastError());
     return ICM_OK;
 }
@@ -1269,7 +1395,6 @@ int icm_snapshot_state(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_snapshot_state: no state (icm_set_state)");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     const size_t T = (size_t)h->T, L = (size_t)h->cfg.L, nc = (size_t)h->max_cells;
     icm_handle::Snapshot& sn = h->snap;
     HIPCHK(h, sn.x.reserve(3 * T)); HIPCHK(h, sn.mapx.reserve(L)); HIPCHK(h, sn.mapy.reserve(L)); HIPCHK(h, sn.counts_new.reserve(L));
@@ -1296,7 +1421,6 @@ int icm_restore_state(icm_handle* h) {
     const size_t T = (size_t)h->T, L = (size_t)h->cfg.L, nc = (size_t)h->max_cells;
     if (!sn.valid || sn.x.cap < 3 * T || sn.g_nb.cap < nc) FAIL(h, ICM_ERR_ARG, "icm_restore_state: no snapshot of this sequence (icm_snapshot_state)");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     hipStream_t st = h->stream;   // stream-ordered behind the last sweep: no synchronisation needed
     HIPCHK(h, hipMemcpyAsync(h->x, sn.x.p, 3 * T * sizeof(double), hipMemcpyDeviceToDevice, st));
     h->rot_valid = false;
@@ -1313,42 +1437,7 @@ int icm_restore_state(icm_handle* h) {
     return ICM_OK;
 }
 
-static SolveArgs solve_args(icm_handle* h) {
-    SolveArgs a;
-    a.x = h->x; a.x0 = h->x0.p; a.odo = h->odo.p; a.u = h->u.p;
-    a.T = (int)h->T; a.t_begin = (int)h->t_begin; a.nloc = (int)h->nloc;
-    a.boff = h->boff.p; a.bx = h->bx.p; a.by = h->by.p; a.btx = h->btx.p; a.bty = h->bty.p;
-    a.per_beam = h->per_beam ? 1 : 0;
-    a.ent_off = h->ent_off.p; a.e_k = h->e_k.p; a.e_b = h->e_b.p;
-    a.tgt = h->tgt.p; a.pose_c = h->pose_c.p; a.pose_m = h->pose_m.p;
-    a.dt = h->cfg.deltat; a.R0 = h->cfg.R[0]; a.R1 = h->cfg.R[1]; a.R2 = h->cfg.R[2];
-    a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
-    a.diag = nullptr;
-    a.rot = h->rot.p;
-    return a;
-}
-
-// Where the pipelined sweep cuts the sequence: at a superchunk boundary (so that chunks, records and
-// matrix rows split cleanly) and therefore at an even pose -- the first segment ends on an odd
-// pose, whose even neighbours on both sides it reads as OLD values, and the second segment's first
-// (even) pose reads that finished odd pose: the red-black order of the whole sequence is kept
-// (k_solve_m_fused, SolveSeg).  0 = the sequence is too short to cut.
-static int pipeline_split_super(const icm_handle* h) {
-    if (h->nsuper < 2) return 0;
-    const int s = (h->nsuper / 2) / kL3Rows * kL3Rows;   // (a whole number of k_lm_l3's row groups: same additions as unsegmented)
-    if (s == 0) return 0;
-    const int64_t M = (int64_t)s * h->chunk_group * h->chunk_poses;
-    return (M >= 2 && M + 1 < h->nloc) ? s : 0;
-}
-
-static bool pipeline_applies(const icm_handle* h, int schedule) {
-    return h->pipeline && h->pipe_ok && schedule == ICM_SCHEDULE_REDBLACK && h->world == 1 && h->t_begin == 0 && h->nloc == h->T &&
-           h->form == 0 && h->fuse_colours && !h->timing && !h->debug && !h->per_beam && !h->brute && h->entry_path != 0 &&
-           h->hier_ok && h->gpu_filtrar && !h->x_external && pipeline_split_super(h) > 0;
-}
-
 static int icm_sweep_classic(icm_handle* h, int schedule) {
-    h->pipe_used = 0;
     const bool req = h->opt_req;
     int rc = ICM_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1365,149 +1454,9 @@ static int icm_sweep_classic(icm_handle* h, int schedule) {
     return rc;
 }
 
-// One red-black sweep with the two time segments software-pipelined over two streams:
-//   main stream   A/B/moments(seg 0) | A/B/moments(seg 1)                 | next sweep: A/B/moments(seg 0) ...
-//   solve stream                     | solves(seg 0)      | solves(seg 1) ...
-// The pose solves are bounded by the serial Nelder-Mead chain of their slowest wave (one wave per
-// SIMD at half the FP64 issue rate), phase A/B by vector issue: side by side they fill the chip.
-// Same kernels, same arithmetic, same order per pose as the unsegmented sweep -- bit-identical results.
-static int icm_sweep_pipelined(icm_handle* h) {
-    HIPCHK(h, hipSetDevice(h->device));
-    const int nloc = (int)h->nloc, L = (int)h->cfg.L;
-    h->scan0_empty = (h->h_boff[1] == h->h_boff[0]);
-    if (h->scan0_empty) return join_solves(h);
-    if (h->h_boff[(size_t)nloc] == h->h_boff[(size_t)nloc - 1])
-        FAIL(h, ICM_ERR_INDEX, "sweep: the last pose has no kept beams (the reference raises IndexError at scripts/ICM_ROS.py:144)");
-    hipStream_t X = h->stream, Y = h->solve_stream, Cs = h->copy_stream;
-    const int CH = h->chunk_poses, G = h->chunk_group, S = h->nsuper, NC = h->nchunks;
-    const int s_split = pipeline_split_super(h), c_split = s_split * G, M = c_split * CH;
-    const int nrec = NC * kT1;
-    double* const pre = reinterpret_cast<double*>(h->e_w.p);
-    const size_t nzs = h->st_stride;
-    double* const ms = h->ms.p;
-    const size_t msn = (size_t)S * (size_t)L;
-    double* const ro = h->rec_off.p;
-    HIPCHK(h, h->x_bak.reserve(3 * (size_t)M));
-    HIPCHK(h, h->l3_carry.reserve(3 * (size_t)L));
-    HIPCHK(h, h->scan_carry.reserve(2));
-    {   // completion flags of the one-launch solves: sized once for the longer segment
-        const int64_t npc = std::max<int64_t>(M, nloc - M) / 2 + 1;
-        const int nwv = (int)((npc + 15) / 16) + 1;   // (enough for the quad form, 16 poses per wave)
-        if (h->solve_flag_waves < nwv) {
-            HIPCHK(h, hipStreamSynchronize(Y));
-            HIPCHK(h, hipStreamSynchronize(X));
-            HIPCHK(h, h->solve_flags.reserve(2 * (size_t)nwv));
-            HIPCHK(h, h->solve_ndef.reserve(1));
-            HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, 2 * (size_t)nwv * sizeof(int), Y));
-            HIPCHK(h, hipMemsetAsync(h->solve_ndef.p, 0, sizeof(unsigned long long), Y));
-            h->solve_flag_waves = nwv;
-            h->solve_epoch = 0;
-        }
-    }
-    h->lact0 = (int)h->lact;
-    h->assoc_kept = false;
-    h->ms_clean = false;
-    const SolveArgs sa = solve_args(h);
-    GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p};
-    HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 16 * sizeof(int), X));
-    for (int seg = 0; seg < 2; ++seg) {
-        const int t0 = seg ? M : 0, t1 = seg ? nloc : M, nseg = t1 - t0;
-        const int c0 = seg ? c_split : 0, c1 = seg ? NC : c_split;
-        const int s0 = seg ? s_split : 0, s1 = seg ? S : s_split;
-        // this segment's poses (and the buffers its solves read) must be final: the previous sweep's solves of it
-        if (h->solves_in_flight) HIPCHK(h, hipStreamWaitEvent(X, h->ev_s[seg], 0));
-        if (seg == 0) HIPCHK(h, hipMemcpyAsync(h->x_bak.p, h->x, 3 * (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, X));
-        const int nbw = nblocks_waves(nseg);
-        k_pose_rot<<<nblocks_threads(nseg), kBlock, 0, X>>>(h->x, h->x0.p, t0, nseg, h->rot.p + 2 * (size_t)t0);
-#define ASSOC_SEG(HS)                                                                                                 \
-    k_assoc_group<false, false, HS><<<nbw, kBlock, 0, X>>>(h->x, h->x0.p, t0, nseg, h->boff.p + t0, h->bx.p, h->by.p, gv,  \
-        h->cfg.dist_thr, h->thr2, h->label.p, h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p + t0, \
-        h->isnew.p + t0, h->flags.p, h->rot.p + 2 * (size_t)t0, (int)h->nnz, h->st_off.p + t0, h->ent_off.p + t0, t0, (int)h->st_sparse0)
-        if (h->hash_slots == 128) ASSOC_SEG(128); else ASSOC_SEG(256);
-#undef ASSOC_SEG
-        const int ntiles = (nseg + kScanTile - 1) / kScanTile;
-        k_scan_tiles<<<ntiles, kBlock, 0, X>>>(h->nent.p + t0, h->isnew.p + t0, h->ent_off.p + t0, h->new_rank.p + t0, h->scan_tot.p, nseg);
-        k_scan_fix<<<ntiles, kBlock, 0, X>>>(h->ent_off.p + t0, h->new_rank.p + t0, h->scan_tot.p, nseg, ntiles,
-                                             seg ? h->scan_carry.p : nullptr, seg ? nullptr : h->scan_carry.p);
-#define CHUNK_L1(CHV)                                                                                                  \
-    k_chunk_l1<CHV><<<nblocks_waves(c1 - c0), kBlock, 0, X>>>(h->x, h->x0.p, 0, nloc, c1, h->st_off.p, h->nent.p, h->ent_off.p, \
-        h->new_rank.p, h->lact0, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, pre, pre + nzs,                          \
-        reinterpret_cast<unsigned*>(pre + 2 * nzs), h->rec_label.p, h->rec_s.p, \
-        h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, c0)
-        if (CH == 64) CHUNK_L1(64); else if (CH == 32) CHUNK_L1(32); else CHUNK_L1(16);
-#undef CHUNK_L1
-        k_chunk_l2<<<s1 - s0, kT1, 0, X>>>(NC, G, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
-                                           ro, ro + nrec, ro + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->flags.p, s0, 1);
-        k_lm_l3<<<(L + kWave - 1) / kWave, kBlock, 0, X>>>(S, L, h->lact0, h->new_rank.p + t1, ms, ms + msn, ms + 2 * msn, nullptr,
-                                                      h->y_raw.p, h->cnt_raw.p, h->ent_off.p + t1, h->flags.p, s0, s1,
-                                                      seg ? h->l3_carry.p : nullptr, seg ? nullptr : h->l3_carry.p, seg);
-        if (seg) HIPCHK(h, hipEventRecord(h->ev_map, X));   // raw map, counts and flags are final: the copy stream takes them from here
-        k_rec_push<<<nblocks_threads((int64_t)(c1 - c0) * kT1), kBlock, 0, X>>>(c1 * kT1, G, L, h->rec_label.p, ms, ms + msn, ms + 2 * msn,
-                                                                               nullptr, nullptr, nullptr, ro, ro + nrec, ro + 2 * (size_t)nrec, c0 * kT1);
-        k_pose_moments_h<<<nblocks_threads((int64_t)nseg * 16), kBlock, 0, X>>>(
-            h->x, h->x0.p, 0, nloc, h->st_off.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p, pre, pre + nzs,
-            reinterpret_cast<const unsigned*>(pre + 2 * nzs), CH, ro, ro + nrec,
-            ro + 2 * (size_t)nrec, h->pose_m.p, nullptr, t0, t1, h->rot.p);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipEventRecord(h->ev_m[seg], X));
-        if (seg == 0) {   // its solves start beside the second segment's phase A/B
-            HIPCHK(h, hipStreamWaitEvent(Y, h->ev_m[0], 0));
-            int rc = launch_fused_solve(h, sa, SolveSeg{0, M, 0, nullptr}, Y);
-            if (rc) return rc;
-            HIPCHK(h, hipEventRecord(h->ev_s[0], Y));
-        }
-    }
-    // Everything else of the sweep is queued WITHOUT a host look at the counts and flags: the kernels
-    // that would replace state (second segment's solves, Mapa.filtrar) check the sweep's flags themselves
-    // and leave the state alone if a table overflowed or the labels exceed L.
-    HIPCHK(h, hipStreamWaitEvent(Y, h->ev_m[1], 0));
-    {
-        int rc = launch_fused_solve(h, sa, SolveSeg{M, nloc, 1, h->flags.p}, Y);
-        if (rc) return rc;
-    }
-    HIPCHK(h, hipEventRecord(h->ev_s[1], Y));
-    h->solves_in_flight = true;
-    // raw map download, the four counters, Mapa.filtrar + search grid: copy stream, beside moments / solves
-    HIPCHK(h, hipStreamWaitEvent(Cs, h->ev_map, 0));
-    {
-        int rc = launch_filtrar(h, Cs, true);   // (first: the next sweep's phase A waits for the new map, not for the downloads)
-        if (rc) return rc;
-    }
-    HIPCHK(h, hipMemcpyAsync(h->pin_i, h->flags.p + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, Cs));
-    HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, Cs));
-    HIPCHK(h, hipEventRecord(h->ev_copied, Cs));
-    h->map_copy_pending = true;
-    // the one host wait of the sweep (the solves are still running)
-    HIPCHK(h, hipEventSynchronize(h->ev_copied));
-    h->E = h->pin_i[0];
-    h->n_new_loc = h->pin_i[1];
-    if (h->pin_i[2] || h->pin_i[3]) {
-        // a per-pose or per-chunk table overflowed: this map is too dense for the pipelined form.  The
-        // map state and the second segment's poses were left alone (device-side checks); the first
-        // segment's solves have run on incomplete targets: put its poses back and take the unsegmented
-        // sweep, which sizes its tables / falls back to the sort-based pipeline itself.
-        HIPCHK(h, hipStreamSynchronize(Y));
-        h->solves_in_flight = false;
-        h->map_copy_pending = false;
-        HIPCHK(h, hipMemcpyAsync(h->x, h->x_bak.p, 3 * (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, X));
-        h->pipe_ok = false;
-        return icm_sweep_classic(h, ICM_SCHEDULE_REDBLACK);
-    }
-    if ((int64_t)h->lact0 + h->n_new_loc > L) {
-        h->map_copy_pending = false;
-        int rcj = join_solves(h);
-        if (rcj) return rcj;
-        FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L (the reference raises IndexError, scripts/ICM_SLAM_tools.py:191)");
-    }
-    h->path_used = 1;
-    h->pipe_used = 1;
-    return icm_sweep_finish(h);
-}
-
 int icm_sweep_device(icm_handle* h, int schedule) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_device: no state (icm_set_state)");
-    if (pipeline_applies(h, schedule)) return icm_sweep_pipelined(h);
     return icm_sweep_classic(h, schedule);
 }
 
@@ -1516,14 +1465,6 @@ int icm_set_optimistic(icm_handle* h, int on) {
     h->opt_req = on != 0;
     return ICM_OK;
 }
-
-int icm_set_pipeline(icm_handle* h, int on) {
-    if (!h) return ICM_ERR_ARG;
-    h->pipeline = on != 0;
-    return ICM_OK;
-}
-
-int icm_get_pipeline_used(const icm_handle* h) { return h ? h->pipe_used : ICM_ERR_ARG; }
 
 // ---- RCCL from inside the library: collectives (the loader is above icm_destroy) ----------------
 #define RCCLCHK(h, call)                                                                                     \
@@ -1557,25 +1498,23 @@ int icm_comm_unique_id(void* id128) {
     return ICM_OK;
 }
 
-int icm_comm_init(icm_handle* h, const void* id128, int rank, int world) {
-    if (!h) return ICM_ERR_ARG;
-    if (!id128 || world < 1 || rank < 0 || rank >= world) FAIL(h, ICM_ERR_ARG, "icm_comm_init: bad arguments");
-    if (!h->uploaded) FAIL(h, ICM_ERR_ARG, "icm_comm_init: upload this rank's shard first (icm_upload)");
-    if (h->comm) FAIL(h, ICM_ERR_ARG, "icm_comm_init: communicator already initialised");
-    if (!rccl_load(h->err)) return ICM_ERR_UNSUPPORTED;
+// Pose blocks of a sharded job: ceil(T / world) rounded up to an EVEN number of poses, so that every shard starts at an
+// even pose (SolveSeg: a shard's ghost pose is odd); rank r owns [r blk, min((r + 1) blk, T)).
+int64_t icm_shard_block(int64_t T, int world) {
+    if (T <= 0 || world <= 0) return 0;
+    const int64_t blk = (T + world - 1) / world;
+    return blk + (blk & 1);
+}
+
+// exchange buffers owned by the library, bound like a caller's would be
+static int comm_setup(icm_handle* h, int rank, int world) {
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
-    const int64_t blk = (h->T + world - 1) / world;
+    const int64_t blk = icm_shard_block(h->T, world);
     if (h->t_begin != std::min<int64_t>((int64_t)rank * blk, h->T) || h->t_begin + h->nloc != std::min<int64_t>((int64_t)(rank + 1) * blk, h->T))
-        FAIL(h, ICM_ERR_ARG, "icm_comm_init: the uploaded shard is not block `rank` of ceil(T / world)-pose blocks");
-    ncclUniqueId id;
-    std::memcpy(&id, id128, sizeof(id));
-    RCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
+        FAIL(h, ICM_ERR_ARG, "icm_comm_init: the uploaded shard is not block `rank` of icm_shard_block(T, world)-pose blocks");
     const size_t stride = (size_t)icm_stats_stride(h);
     HIPCHK(h, h->own_stats_all.reserve((size_t)world * stride));
     HIPCHK(h, h->own_stats_send.reserve(stride));
-    HIPCHK(h, h->own_halo_send.reserve(8));
-    HIPCHK(h, h->own_halo_all.reserve(6 * (size_t)world + 2));
     HIPCHK(h, h->own_poses.reserve((size_t)world * (size_t)blk * 3));
     HIPCHK(h, hipMemsetAsync(h->own_stats_all.p, 0, (size_t)world * stride * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->own_stats_send.p, 0, stride * sizeof(double), h->stream));
@@ -1585,7 +1524,35 @@ int icm_comm_init(icm_handle* h, const void* id128, int rank, int world) {
     int rc;
     if ((rc = icm_bind_exchange(h, h->own_stats_all.p, rank, world))) return rc;
     if ((rc = icm_bind_pose_buffer(h, h->own_poses.p))) return rc;
-    return icm_bind_exchange_send(h, h->own_stats_send.p, h->own_halo_send.p, h->own_halo_all.p);
+    if ((rc = icm_bind_exchange_send(h, h->own_stats_send.p))) return rc;
+    h->comm_ready = true;
+    return ICM_OK;
+}
+
+int icm_comm_init(icm_handle* h, const void* id128, int rank, int world) {
+    if (!h) return ICM_ERR_ARG;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) FAIL(h, ICM_ERR_ARG, "icm_comm_init: bad arguments");
+    if (!h->uploaded) FAIL(h, ICM_ERR_ARG, "icm_comm_init: upload this rank's shard first (icm_upload)");
+    if (h->comm_ready) FAIL(h, ICM_ERR_ARG, "icm_comm_init: communicator already initialised");
+    if (!rccl_load(h->err)) return ICM_ERR_UNSUPPORTED;
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    RCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
+    return comm_setup(h, rank, world);
+}
+
+// The same sharded driver over a caller-supplied all-gather instead of RCCL (MPI, a test harness carrying the messages
+// through host memory, ...): `fn` must gather `count` doubles from every rank's `send` into `recv` (rank-major), ordered
+// after the work already queued on `hip_stream` and complete -- or stream-ordered -- when it returns; non-zero = failure.
+int icm_comm_init_transport(icm_handle* h, int rank, int world, icm_allgather_fn fn, void* user) {
+    if (!h) return ICM_ERR_ARG;
+    if (!fn || world < 1 || rank < 0 || rank >= world) FAIL(h, ICM_ERR_ARG, "icm_comm_init_transport: bad arguments");
+    if (!h->uploaded) FAIL(h, ICM_ERR_ARG, "icm_comm_init_transport: upload this rank's shard first (icm_upload)");
+    if (h->comm_ready) FAIL(h, ICM_ERR_ARG, "icm_comm_init_transport: communicator already initialised");
+    h->transport = fn;
+    h->transport_user = user;
+    return comm_setup(h, rank, world);
 }
 
 int icm_comm_destroy(icm_handle* h) {
@@ -1596,17 +1563,31 @@ int icm_comm_destroy(icm_handle* h) {
         (void)g_rccl.CommDestroy(h->comm);
         h->comm = nullptr;
     }
+    h->transport = nullptr;
+    h->transport_user = nullptr;
+    h->comm_ready = false;
     return ICM_OK;
 }
 
-// One red-black sweep of a sharded sequence, the collectives issued here, on the handle's stream:
-// local phase A + statistics -> all-gather of the [3L+8] statistics -> targets -> odd poses ->
-// all-gather of the 48-byte halos -> even poses -> Mapa.filtrar (replicated).  
+static int all_gather(icm_handle* h, const double* send, double* recv, size_t count) {
+    if (h->transport) {
+        if (h->transport(send, recv, count, reinterpret_cast<void*>(h->stream), h->transport_user))
+            FAIL(h, ICM_ERR_HIP, "the caller's all-gather (icm_comm_init_transport) failed");
+        return ICM_OK;
+    }
+    RCCLCHK(h, g_rccl.AllGather(send, recv, count, ncclDouble, h->comm, h->stream));
+    return ICM_OK;
+}
+
+// One red-black sweep of a sharded sequence with its ONE collective issued here, on the handle's stream (SURVEY 8e,
+// scripts/ICM_ROS.py:141-158 sharded over poses): local phase A + statistics -> all-gather of the [3L + 16]
+// statistics (landmark sums, new-landmark count, flags, the shard's boundary poses of the previous sweep) -> targets
+// + the ghost pose's moments -> both colours of the shard in one launch -> Mapa.filtrar (replicated).
 static int sweep_sharded_once(icm_handle* h);
 
 int icm_sweep_sharded(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
-    if (!h->comm) FAIL(h, ICM_ERR_ARG, "icm_sweep_sharded: no communicator (icm_comm_init)");
+    if (!h->comm_ready) FAIL(h, ICM_ERR_ARG, "icm_sweep_sharded: no communicator (icm_comm_init)");
     // queued whole first; if ANY rank's tables overflowed every rank sees it (the flags travel with the statistics),
     // nothing was replaced anywhere, and every rank repeats the sweep with its host looking in the middle
     const bool req = h->opt_req;
@@ -1621,38 +1602,43 @@ int icm_sweep_sharded(icm_handle* h) {
 }
 
 static int sweep_sharded_once(icm_handle* h) {
-    int rc;
-    if ((rc = icm_sweep_local(h))) return rc;
     const size_t stride = (size_t)icm_stats_stride(h);
-    RCCLCHK(h, g_rccl.AllGather(h->own_stats_send.p, h->own_stats_all.p, stride, ncclDouble, h->comm, h->stream));
-    if ((rc = icm_sweep_targets(h))) return rc;
-    if (h->world == 1) {   // no neighbour, no halo: both colours in the one-launch solve
-        if ((rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, -1))) return rc;
-        return icm_sweep_finish(h);
+    // A rank that fails on its own in phase A (careful form: a table too small even at its largest size, labels beyond L,
+    // a no-beam last pose) must not leave the others waiting in the collective: it still sends its message, with the
+    // error code in the header, and every rank returns that error after the exchange.
+    const int rc_local = icm_sweep_local(h);
+    if (rc_local == ICM_ERR_HIP || rc_local == ICM_ERR_ARG) return rc_local;   // (not a property of the data: nothing sensible to exchange)
+    const std::string err_local = h->err;
+    int rc;
+    if (rc_local && (rc = icm_mark_failed(h, rc_local))) return rc;
+    rc = all_gather(h, h->own_stats_send.p, h->own_stats_all.p, stride);
+    if (rc) return rc;
+    if (!h->optimistic || rc_local) {
+        // careful form: the host looks at every rank's header ([1] >= 2: that rank failed with code 1 - [1])
+        int fr = -1, code = 0;
+        if ((rc = icm_failed_rank(h, &fr, &code))) return rc;
+        if (rc_local) { h->err = err_local; return rc_local; }
+        if (fr >= 0)
+            FAIL(h, code, "sharded sweep: rank " + std::to_string(fr) + " failed in phase A (" + (code == ICM_ERR_INDEX ? "IndexError: labels beyond L or a no-beam last pose" : code == ICM_ERR_CAPACITY ? "a scan touched more distinct landmarks than supported" : "error") + ")");
     }
-    if ((rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, 1))) return rc;
-    RCCLCHK(h, g_rccl.AllGather(h->own_halo_send.p, h->own_halo_all.p, 6, ncclDouble, h->comm, h->stream));
-    if ((rc = icm_halo_unpack(h))) return rc;
-    if ((rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, 0))) return rc;   // (its boundary values ride in the next statistics message)
+    if ((rc = icm_sweep_targets(h))) return rc;
+    if ((rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, -1))) return rc;
     return icm_sweep_finish(h);
 }
 
 // Every rank's pose block -> every rank (before icm_get_state on a sharded handle).
 int icm_gather_poses(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
-    if (!h->comm) FAIL(h, ICM_ERR_ARG, "icm_gather_poses: no communicator (icm_comm_init)");
+    if (!h->comm_ready) FAIL(h, ICM_ERR_ARG, "icm_gather_poses: no communicator (icm_comm_init)");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     const size_t cnt = (size_t)h->comm_blk * 3;
-    RCCLCHK(h, g_rccl.AllGather(h->own_poses.p + (size_t)h->rank * cnt, h->own_poses.p, cnt, ncclDouble, h->comm, h->stream));
-    return ICM_OK;
+    return all_gather(h, h->own_poses.p + (size_t)h->rank * cnt, h->own_poses.p, cnt);
 }
 
 int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out, int64_t* K_out) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_get_state: no state");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     {
         int rc = sync_host_map(h);
         if (rc) return rc;
@@ -1694,7 +1680,6 @@ int icm_get_association(icm_handle* h, int32_t* labels, double* target_x, double
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_get_association: no sweep has run");
     if (!h->assoc_kept) FAIL(h, ICM_ERR_ARG, "icm_get_association: enable icm_set_debug before the sweep");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t nz = (size_t)h->nnz;
     if (!nz) return ICM_OK;
@@ -1808,7 +1793,6 @@ int icm_filtrar_device(icm_handle* h, const double* y, const double* counts, int
     if (lact < 0 || lact > (int64_t)L) FAIL(h, ICM_ERR_ARG, "icm_filtrar_device: landmarks_actuales outside [0, L]");
     if (h->world > 1) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_filtrar_device: not on a handle bound to a multi-rank exchange");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     {
         int rc = reserve_map_buffers(h);
         if (rc) return rc;
@@ -1962,7 +1946,6 @@ int icm_init_pass(icm_handle* h, const double* x0, double* y, double* counts, in
     const size_t lds = (size_t)maxb * (4 * sizeof(double) + sizeof(int));
     if (lds > 160 * 1024) FAIL(h, ICM_ERR_UNSUPPORTED, "icm_init_pass: too many kept beams per scan for the LDS staging");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     DevBuf<double> dx, dy, dc;
     DevBuf<int> di;
     HIPCHK(h, dx.reserve(3 * T)); HIPCHK(h, dy.reserve(2 * L)); HIPCHK(h, dc.reserve(L)); HIPCHK(h, di.reserve(2));
@@ -2054,7 +2037,6 @@ int icm_get_solve_diag(icm_handle* h, double* out) {
     if (!h || !out) return ICM_ERR_ARG;
     if (!h->diag.p) FAIL(h, ICM_ERR_ARG, "icm_get_solve_diag: enable icm_set_debug before the sweep");
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcj = join_solves(h); if (rcj) return rcj; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->diag.p, 3 * (size_t)h->T * sizeof(double), hipMemcpyDeviceToHost));
     return ICM_OK;
@@ -2091,13 +2073,40 @@ int icm_set_fused_spin_limit(icm_handle* h, int polls) {
 int icm_get_fused_deferred(icm_handle* h, int64_t* waves) {
     if (!h || !waves) return ICM_ERR_ARG;
     *waves = 0;
-    if (!h->solve_ndef.p) return ICM_OK;
+    if (!h->solve_counts.p) return ICM_OK;
     HIPCHK(h, hipSetDevice(h->device));
     unsigned long long v = 0;
-    HIPCHK(h, hipMemcpyAsync(&v, h->solve_ndef.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&v, h->solve_counts.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *waves = (int64_t)v;
     return ICM_OK;
+}
+
+int icm_get_fixup_poses(icm_handle* h, int64_t* poses) {
+    if (!h || !poses) return ICM_ERR_ARG;
+    *poses = 0;
+    if (!h->solve_counts.p) return ICM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long v = 0;
+    HIPCHK(h, hipMemcpyAsync(&v, h->solve_counts.p + 1, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *poses = (int64_t)v;
+    return ICM_OK;
+}
+
+int icm_set_fold_mode(icm_handle* h, int mode) {
+    if (!h) return ICM_ERR_ARG;
+    if (mode < -1 || mode > 1) FAIL(h, ICM_ERR_ARG, "icm_set_fold_mode: mode must be -1, 0 or 1");
+    h->fold_mode = mode;
+    return ICM_OK;
+}
+
+int icm_staging_layout(int64_t nnz, int64_t nloc, int64_t* out3) {
+    if (!out3) return ICM_ERR_ARG;
+    StagingLayout l;
+    const bool ok = staging_layout(nnz, nloc, l);
+    out3[0] = l.sparse0; out3[1] = l.entries; out3[2] = l.prefix_stride;
+    return ok ? ICM_OK : ICM_ERR_CAPACITY;
 }
 
 int icm_set_entry_path(icm_handle* h, int mode) {

@@ -393,6 +393,17 @@ __device__ __forceinline__ double pose_energy_folded(const PoseFold& f, double p
     return fma_(f.A, rr, fma_(dx, l1, fma_(dy, l2, l3)));
 }
 
+// The folded form alone (k_solve_m_fused<., true>): the value is used whatever it is worth, `ok` says whether this
+// lane's heading step stayed inside the form's validity range.  A pose with one evaluation outside it is not
+// stored by that kernel but marked, and the fix-up launch behind it solves it with pose_energy_moments() below
+// (folded where valid, term by term elsewhere): the main kernel then keeps neither the context nor the moment
+// sums alive across the Nelder-Mead loop -- thirteen coefficients, no scratch.
+__device__ __forceinline__ double pose_energy_fold_only(const PoseFold& f, double px, double py, double th, bool& ok) {
+    const double dl = th - f.tho;
+    ok = fabs(dl) <= f.dlim;   // (NaN -> false)
+    return pose_energy_folded(f, px, py, dl);
+}
+
 __device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const PoseMoments& m, const PoseFold& f, double px,
                                                       double py, double th) {
     const double dl = th - f.tho;
@@ -538,8 +549,13 @@ __device__ __forceinline__ double amax3(const Vtx& a, const Vtx& b) {
 // entered shrink loop, and one for the four initial vertices.  Four inlined copies of the
 // energy in total, and no per-evaluation state dispatch.
 // out = {x, y, theta, f, nit, nfev}.
-template <class F>
-__device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double st, double out[6]) {
+// `stop` (optional): a per-lane predicate looked at once per iteration beside SciPy's own termination test; a lane
+// for which it holds leaves the loop (its result is discarded by the caller: fold-only solves).
+struct NeverStop {
+    __device__ __forceinline__ bool operator()() const { return false; }
+};
+template <class F, class S = NeverStop>
+__device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double st, double out[6], S stop = S()) {
     const int maxfun = 600, maxiter = 600;
     const double xatol = 1e-3, fatol = 1e-4;
     const double grow = 1 + 0.05;
@@ -572,7 +588,7 @@ __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double s
     while (nfev < maxfun && it < maxiter) {
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
-        if (dx <= xatol && df <= fatol) break;
+        if ((dx <= xatol && df <= fatol) || stop()) break;
         const double bx = div3((v0.x + v1.x) + v2.x);
         const double by = div3((v0.y + v1.y) + v2.y);
         const double bt = div3((v0.t + v1.t) + v2.t);
@@ -652,8 +668,17 @@ __device__ __forceinline__ double quad_bcast(double v) {  // value of lane K of 
     return __hiloint2double(hi, lo);
 }
 
-template <class F>
-__device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, double st, int role, double out[6]) {
+// true in all four lanes of a DPP quad when it holds in one of them
+__device__ __forceinline__ bool quad_any(bool b) {
+    int v = b ? 1 : 0;
+    v |= __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
+    v |= __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
+    return v != 0;
+}
+
+// (`stop` must be uniform over the quad: its four lanes take every decision together)
+template <class F, class S = NeverStop>
+__device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, double st, int role, double out[6], S stop = S()) {
     const int maxfun = 600, maxiter = 600;
     const double xatol = 1e-3, fatol = 1e-4;
     const double grow = 1 + 0.05;
@@ -680,7 +705,7 @@ __device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, dou
     while (nfev < maxfun && it < maxiter) {
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
-        if (dx <= xatol && df <= fatol) break;
+        if ((dx <= xatol && df <= fatol) || stop()) break;
         const double bx = div3((v0.x + v1.x) + v2.x);
         const double by = div3((v0.y + v1.y) + v2.y);
         const double bt = div3((v0.t + v1.t) + v2.t);

@@ -306,4 +306,13 @@ int cluster_first_scan_host(const double* pts, int64_t n64, double t, int32_t* l
     return ICM_OK;
 }
 
+bool staging_layout(int64_t nnz, int64_t nloc, StagingLayout& out) {
+    const int64_t nz = nnz > 1 ? nnz : 1;   // (an all-empty sequence still gets one place)
+    const int64_t np = nloc > 0 ? nloc : 0;
+    out.sparse0 = nz + (int64_t)kStageSlack * np + kStageWave;
+    out.entries = out.sparse0 + nz + kStagePad;
+    out.prefix_stride = out.entries + kStageWave;
+    return nnz >= 0 && nloc >= 0 && out.prefix_stride <= (int64_t)0x7fffffff;
+}
+
 }  // namespace icm

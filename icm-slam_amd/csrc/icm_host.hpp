@@ -27,6 +27,23 @@ void build_grid(const double* map_x, const double* map_y, int64_t K, double dist
 int filtrar_host(const icm_config& cfg, const double* y, const double* counts, int64_t lact,
                  double* y_out, double* counts_out, int64_t* lact_out, std::string& err);
 
+// The ONE place that sizes the staging area of phase A's (pose, landmark) entries and everything indexed like it.
+//   [0, sparse0)            packed area: pose t owns [plan[t] + kStageSlack t, plan[t+1] + kStageSlack (t+1)), plan = the
+//                           previous sweep's exclusive scan of the entry counts (<= nnz in total)
+//   [sparse0, entries)      sparse area: a pose whose entries do not fit its reserved place stages them at
+//                           sparse0 + (offset of its first kept beam); at most one entry per kept beam
+//   entries                 capacity of st_label / st_k / st_sx / st_sy
+//   prefix_stride           capacity of EACH per-entry prefix array (pre_x, pre_y, pre_n): one element per staging
+//                           place plus one wave of slack for the branch-free stores of idle lanes
+// false: the sequence has too many kept beams for 32-bit entry offsets.
+constexpr int kStageSlack = 4;
+constexpr int kStagePad = 512;
+constexpr int kStageWave = 64;
+struct StagingLayout {
+    int64_t sparse0 = 0, entries = 0, prefix_stride = 0;
+};
+bool staging_layout(int64_t nnz, int64_t nloc, StagingLayout& out);
+
 // First-scan clustering of Mapa.actualizar's Lact == 0 branch (reference
 // scripts/ICM_SLAM_tools.py:160-165): fcluster(linkage(pdist(pts)), t) - 1, i.e. SciPy's single
 // linkage, depth-2 inconsistency coefficients and the 'inconsistent' flat-cluster rule.

@@ -647,7 +647,7 @@ __device__ __forceinline__ void seg_step_rows(bool take, double& ax, double& ay)
 // range in the sparse area behind the packed one -- always correct, dense once the counts have settled (on S2 every pose
 // from the second sweep on).  The readers stream a pose's ~37 entries from consecutive memory instead of from the front of
 // every 230-beam range.
-constexpr int kStageSlack = 4;
+// (kStageSlack and the sizes of the staging area: staging_layout, icm_host.hpp)
 
 // HS = hash slots per pose; at most 3/4 of them may be used (distinct landmarks of one scan).
 // HS = 128 keeps the kernel at 14 KB of LDS and 64 VGPRs = 8 waves per SIMD (the kernel waits
@@ -2072,6 +2072,14 @@ struct SolveArgs {
     double* diag;         // optional (T,3): f, nit, nfev per pose
     double* rot;          // optional (nloc,2): (cos, sin)(theta - pi/2) of the solved pose, the table phase A and the
                           // moment kernel of the NEXT sweep read (k_pose_rot's values: whoever writes a pose writes its pair)
+    // fold-only solves (k_solve_m_fused<., true>) and their fix-up (k_solve_m_fix):
+    int* need;            // [nloc + 1], slot tl + 1 (slot 0 = the ghost pose): epoch of the launch that left the pose to the fix-up
+    int* need_seen;       // one word: the latest epoch in which any pose was marked (the fix-up launches look here first)
+    int epoch;
+    // ghost pose of a shard (rank > 0): the lower neighbour's last pose t_begin - 1, solved redundantly so that the
+    // shard's first even pose needs nothing from another rank in the middle of the sweep (local index tl = -1)
+    int ghost_n;          // its kept beams (0: none)
+    const double* ghost_m;   // its 17 moment sums, contiguous (k_ghost_moments)
 };
 
 // Result of one pose solve -> x (write-through when other waves of the same launch wait for it) and the rotation table.
@@ -2085,7 +2093,7 @@ __device__ __forceinline__ void store_pose(const SolveArgs& a, int tg, const dou
         a.x[3 * (size_t)tg + 1] = res[1];
         a.x[3 * (size_t)tg + 2] = res[2];
     }
-    if (a.rot) {
+    if (a.rot && tg >= a.t_begin) {   // (the ghost's pair is recomputed from its owner's value: k_halo_from_headers)
         double ct, st;
         pose_rot(res[2], ct, st);
         a.rot[2 * (size_t)(tg - a.t_begin)] = ct;
@@ -2272,12 +2280,80 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
     }
 }
 
+// Moments of a shard's GHOST pose (the lower neighbour's last pose t_begin - 1, which this rank solves as well:
+// SolveSeg).  Its kept beams were associated and grouped by a one-pose launch of k_assoc_group into the ghost's own
+// staging arrays; its targets are the running means through the ghost pose INCLUSIVE, i.e. the totals over all lower
+// ranks -- exactly what k_stats_prefix left in off_* for the landmarks of mapa_viejo.  A landmark the ghost pose itself
+// created is the last new landmark of the rank below: its one-pose statistics sit in that rank's slot of the exchange
+// buffer at column lact0 + n_new - 1.  Same sums, same formulas as k_pose_moments_h; one wave.
+__global__ __launch_bounds__(kWave) void k_ghost_moments(const double* __restrict__ x, int tg, const int* __restrict__ nent,
+                                                        const int* __restrict__ st_off, const int* __restrict__ st_label,
+                                                        const unsigned short* __restrict__ st_k, const double* __restrict__ st_sbx,
+                                                        const double* __restrict__ st_sby, const double* __restrict__ s2,
+                                                        const double* __restrict__ rot, const double* __restrict__ off_x,
+                                                        const double* __restrict__ off_y, const double* __restrict__ off_n,
+                                                        const double* __restrict__ stats_below, int L, int lact0,
+                                                        double* __restrict__ gm, const int* __restrict__ gflags, int* __restrict__ flags) {
+    const int lane = lane_id();
+    const int n = nent[0], j0 = st_off[0];
+    const double px = x[3 * (size_t)tg], py = x[3 * (size_t)tg + 1];
+    const double ct = rot[0], st = rot[1];
+    double m[kMomentCount];
+#pragma unroll
+    for (int q = 0; q < kMomentCount; ++q) m[q] = 0.0;
+    double mxx = 0.0, mxy = 0.0, myy = 0.0;
+    bool bad = false;
+    for (int q = lane; q < n; q += kWave) {
+        const int lab = st_label[j0 + q];
+        const double k = (double)st_k[j0 + q], sbx = st_sbx[j0 + q], sby = st_sby[j0 + q];
+        double sx, sy, sn;
+        if (lab >= 0) {
+            sx = off_x[lab]; sy = off_y[lab]; sn = off_n[lab];
+        } else {   // the landmark this very pose created: the last new one of the rank below
+            const int c = lact0 + (int)stats_below[3 * (size_t)L] - 1;
+            const bool okc = c >= lact0 && c < L;
+            bad |= !okc;
+            sx = okc ? stats_below[c] : 0.0; sy = okc ? stats_below[(size_t)L + c] : 0.0; sn = okc ? stats_below[2 * (size_t)L + c] : 1.0;
+        }
+        const double tx = sx / sn, ty = sy / sn;
+        const double wx = (ct * sbx - st * sby) / k, wy = (st * sbx + ct * sby) / k;
+        const double rx = (px + wx) - tx, ry = (py + wy) - ty;
+        m[0] += k; m[1] += k * wx; m[2] += k * wy; m[3] += k * rx; m[4] += k * ry;
+        m[5] += k * wx * wx; m[6] += k * wy * wy; m[7] += k * wx * wy;
+        m[8] += k * wx * rx; m[9] += k * wy * rx; m[10] += k * wx * ry; m[11] += k * wy * ry;
+        m[12] += k * rx * rx; m[13] += k * ry * ry;
+        mxx += sbx * sbx / k;
+        mxy += sbx * sby / k;
+        myy += sby * sby / k;
+    }
+#pragma unroll
+    for (int q = 0; q < kMomentCount; ++q) m[q] = wave_sum(m[q]);
+    mxx = wave_sum(mxx);
+    mxy = wave_sum(mxy);
+    myy = wave_sum(myy);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kMomentCount; ++q) gm[q] = m[q];
+        gm[14] = s2[0] - mxx;
+        gm[15] = s2[1] - mxy;
+        gm[16] = s2[2] - myy;
+    }
+    // (the ghost's tables can only overflow where its owner's did, and the owner's flag travelled with its statistics;
+    // a label column out of range likewise means the labels exceed L on every rank)
+    if (__ballot(bad) != 0ull || gflags[0]) {
+        if (lane == 0) flags[0] = 1;
+    }
+}
+
 // One LANE (QUAD: one DPP quad, role = lane & 3) solves pose tg with the moment-form energy.
 // `prev` = x[:,tg-1] as it stands now.
-template <bool QUAD>
-__device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, const double prev[3], double res[3], int role = 0) {
-    const int tl = tg - a.t_begin;
-    const int n = a.boff[tl + 1] - a.boff[tl];
+// FOLD: the Nelder-Mead evaluates the folded form only (pose_energy_fold_only) and the function returns false -- res
+// then means nothing -- as soon as one evaluation of this pose left the form's validity range: the caller marks the
+// pose for the fix-up launch, which repeats the solve with FOLD = false (folded where valid, term by term elsewhere).
+template <bool QUAD, bool FOLD = false>
+__device__ __forceinline__ bool solve_pose_moments(const SolveArgs& a, int tg, const double prev[3], double res[3], int role = 0) {
+    const int tl = tg - a.t_begin;   // (-1: the shard's ghost pose)
+    const int n = tl < 0 ? a.ghost_n : a.boff[tl + 1] - a.boff[tl];
     const bool last = tg + 1 >= a.T;
     if (n == 0) {  // no beams (scripts/ICM_ROS.py:143-147)
         const double* nx = a.x + 3 * (size_t)(tg + 1);
@@ -2285,7 +2361,7 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
         res[0] = (p0 + nx[0]) / 2.0;
         res[1] = (p1 + nx[1]) / 2.0;
         res[2] = (p2 + nx[2]) / 2.0;
-        return;
+        return true;
     }
     SolveCtx c;
     c.dt = a.dt; c.R0 = a.R0; c.R1 = a.R1; c.R2 = a.R2; c.Q0 = a.Q0; c.Q1 = a.Q1; c.cte = a.cte;
@@ -2300,8 +2376,8 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
     }
     make_ctx(c, !last, prev, xp, ua, ut, oa, ot, op);
     PoseMoments m;
-    const double* pm = a.pose_m + tl;
-    const size_t st_ = (size_t)a.nloc;
+    const double* pm = tl < 0 ? a.ghost_m : a.pose_m + tl;
+    const size_t st_ = tl < 0 ? (size_t)1 : (size_t)a.nloc;
     m.S = pm[0]; m.Swx = pm[st_]; m.Swy = pm[2 * st_]; m.Srx = pm[3 * st_]; m.Sry = pm[4 * st_];
     m.Swxx = pm[5 * st_]; m.Swyy = pm[6 * st_]; m.Swxy = pm[7 * st_]; m.Swxrx = pm[8 * st_]; m.Swyrx = pm[9 * st_];
     m.Swxry = pm[10 * st_]; m.Swyry = pm[11 * st_]; m.Srxx = pm[12 * st_]; m.Sryy = pm[13 * st_];
@@ -2321,36 +2397,67 @@ __device__ __forceinline__ void solve_pose_moments(const SolveArgs& a, int tg, c
         sx = c.gax; sy = c.gay; st = c.gat;
     }
     double out[6];
-    if (QUAD)
+    if (FOLD) {
+        bool inside = true;   // every evaluation so far stayed inside the folded form's range (quad: of the whole quad)
+        auto ef = [&](double px, double py, double th) {
+            bool ok;
+            const double e = pose_energy_fold_only(f, px, py, th, ok);
+            inside &= QUAD ? !quad_any(!ok) : ok;
+            return e;
+        };
+        auto stop = [&]() { return !inside; };
+        if (QUAD) nelder_mead3_quad(ef, sx, sy, st, role, out, stop);
+        else nelder_mead3(ef, sx, sy, st, out, stop);
+        if (!inside) return false;
+    } else if (QUAD) {
         nelder_mead3_quad([&](double px, double py, double th) { return pose_energy_moments(c, m, f, px, py, th); }, sx, sy, st, role, out);
-    else
+    } else {
         nelder_mead3([&](double px, double py, double th) { return pose_energy_moments(c, m, f, px, py, th); }, sx, sy, st, out);
+    }
     res[0] = out[0]; res[1] = out[1]; res[2] = out[2];
     if (a.diag && role == 0) {
         a.diag[3 * (size_t)tg] = out[3];
         a.diag[3 * (size_t)tg + 1] = out[4];
         a.diag[3 * (size_t)tg + 2] = out[5];
     }
+    return true;
 }
 
-// Red-black half sweep, moment form: one LANE per pose of the colour (64 poses per wave).
-// abort (nullable): the sweep's flags; any of [0..2] set = leave the poses alone (a sweep queued without a host look).
-__global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colour, const int* __restrict__ abort = nullptr) {
-    if (abort && (abort[0] | abort[1] | abort[2])) return;
+// A time segment of the sequence solved by one launch: poses [t0, t1).  shift = 0 for the segment
+// that starts at pose 0 (which is never solved), 1 for a segment that starts at an even pose > 0:
+//   odd poses   o_j = t0 + 1 + 2 j
+//   even poses  e_j = t0 + 2 j + 2 (1 - shift)      -> e_j reads o_{j - shift} and o_{j - shift + 1}
+// (the first even pose of a shift-1 segment reads the last pose of the segment before, which the
+// stream has finished by then).  Splitting the sequence at an even pose keeps the red-black order:
+// every segment's odd poses read only old even poses, its even poses only finished odd ones.
+// A SHARD [a, b) of a multi-rank job (a even, a > 0) is the segment t0 = a - 2, shift = 0: its first odd pose
+// o_0 = a - 1 is the GHOST -- the lower neighbour's last pose, solved here as well from replicated inputs (its
+// kept beams, its moments from k_ghost_moments, its neighbours' previous-sweep values out of the statistics
+// header) -- so that the shard's first even pose a finds its odd neighbour in this launch and the sweep needs
+// no exchange between its two colours (scripts/ICM_ROS.py:141-158: pose t reads t - 1 and t + 1 only).
+struct SolveSeg {
+    int t0, t1, shift;
+    const int* abort;   // nullable: the sweep's flags; any of [0..2] set = leave the poses alone
+};
+
+__device__ __forceinline__ int seg_pose(const SolveSeg& g, bool even, int j) {
+    return g.t0 + 2 * j + (even ? 2 * (1 - g.shift) : 1);
+}
+
+// Red-black half sweep over a segment, moment form: one LANE per pose of the colour (64 poses per wave).
+__global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, SolveSeg g, int colour) {
+    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;
     const int lane = lane_id();
-    constexpr int LPW = kWave;
-    const int w = (blockIdx.x * kWavesPerBlock + wave_in_block()) * LPW + lane;
-    int first = a.t_begin > 1 ? a.t_begin : 1;
-    if ((first & 1) != colour) ++first;
-    const int tg = first + 2 * w;
-    if (tg >= a.t_begin + a.nloc) return;
+    const int j = (blockIdx.x * kWavesPerBlock + wave_in_block()) * kWave + lane;
+    const int tg = seg_pose(g, colour == 0, j);
+    if (tg >= g.t1) return;
     double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
     double res[3];
     solve_pose_moments<false>(a, tg, prev, res);
     store_pose(a, tg, res, false);
 }
 
-// Both half sweeps of an unsharded red-black sweep in ONE launch.  An even pose reads only its
+// Both half sweeps of a red-black sweep in ONE launch.  An even pose reads only its
 // two odd neighbours, so an even wave need not wait for the slowest odd pose of the whole
 // sequence (which is what a kernel boundary between the colours does) but only for the two odd
 // waves that hold its poses' neighbours.  Waves [0, nw) solve the odd poses and publish a
@@ -2359,7 +2466,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
 // Forward progress does NOT rest on dispatch order: an even wave polls at most `spin_limit`
 // times; if its flags have not arrived by then it marks itself in `deferred[]`, touches nothing
 // and exits (freeing its slot for whatever odd waves are still waiting to be dispatched).
-// k_solve_m_deferred, launched right behind on the same stream, solves exactly the marked waves
+// k_solve_m_fix, launched right behind on the same stream, solves exactly the marked waves
 // -- behind the kernel boundary every odd pose is final -- and clears the marks.  With the
 // observed dispatch (lower workgroup ids first) no wave ever defers and that launch is empty;
 // under any other dispatch order the sweep is slower, never wrong and never stuck.
@@ -2369,30 +2476,40 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, int colo
 // final); consumer = relaxed polls, ONE agent acquire fence, vmcnt(0), then plain loads.  The odd waves that READ an even wave's poses (as the old values of
 // their neighbours) are exactly the two it waits for, so nothing is overwritten while in use.
 // QUAD: the latency form (one DPP quad per pose, 16 poses per wave) with the same dependency rule.
-// A time segment of the sequence solved by one launch: poses [t0, t1).  shift = 0 for the segment
-// that starts at pose 0 (which is never solved), 1 for a segment that starts at an even pose > 0:
-//   odd poses   o_j = t0 + 1 + 2 j
-//   even poses  e_j = t0 + 2 j + 2 (1 - shift)      -> e_j reads o_{j - shift} and o_{j - shift + 1}
-// (the first even pose of a shift-1 segment reads the last pose of the segment before, which the
-// stream has finished by then).  Splitting the sequence at an even pose keeps the red-black order:
-// every segment's odd poses read only old even poses, its even poses only finished odd ones.
-struct SolveSeg {
-    int t0, t1, shift;
-    const int* abort;   // nullable: the sweep's flags; any of [0..2] set = leave the poses alone
-};
-
-template <bool QUAD>
+//
+// FOLD: the lanes evaluate the folded form of the energy ONLY (thirteen coefficients per pose, no context, no
+// moment sums, no scratch).  A pose one of whose evaluations leaves the form's validity range is not stored:
+// its lane writes the launch's epoch into need[] (write-through, like a pose) and the fix-up launches solve it
+// with the complete energy.  An even pose next to a marked odd one cannot be solved here either (its neighbour
+// is not final): it marks itself too.  Marking is decided per pose from the pose's own data, and the fix-up
+// runs the arithmetic the FOLD = false kernel runs, so the sweep's result does not depend on which road a pose took.
+template <bool QUAD, bool FOLD>
 __device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, const SolveSeg& g, bool even, int wv, int lane) {
     constexpr int PPW = QUAD ? kWave / 4 : kWave;   // poses per wave
     const int role = QUAD ? (lane & 3) : 0;
     const int j = wv * PPW + (QUAD ? lane >> 2 : lane);
-    const int tg = g.t0 + 2 * j + (even ? 2 * (1 - g.shift) : 1);
+    const int tg = seg_pose(g, even, j);
     if (tg < g.t1) {   // (whole quads together)
-        double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
+        const int q = tg - a.t_begin + 1;   // slot of need[]
+        bool solved = true;
         double res[3];
-        solve_pose_moments<QUAD>(a, tg, prev, res, role);
-        // (odd poses are handed to the even waves of this launch: write-through (sc1) stores, no cache-wide release needed)
-        if (role == 0) store_pose(a, tg, res, !even);
+        if (FOLD && even) {   // a neighbour left to the fix-up is not final
+            const bool dep = (a.need[q - 1] == a.epoch) | (tg + 1 < g.t1 && a.need[q + 1] == a.epoch);
+            solved = !dep;
+        }
+        if (solved) {
+            double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
+            solved = solve_pose_moments<QUAD, FOLD>(a, tg, prev, res, role);
+        }
+        if (role == 0) {
+            // (odd poses are handed to the even waves of this launch: write-through (sc1) stores, no cache-wide release needed)
+            if (solved) {
+                store_pose(a, tg, res, !even);
+            } else {
+                __hip_atomic_store(&a.need[q], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.need_seen, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every writer stores the same value)
+            }
+        }
     }
 }
 
@@ -2402,13 +2519,14 @@ __device__ unsigned long long g_wave_ts[4 * 16384];
 #else
 #define WAVE_TS(slot) do { } while (0)
 #endif
-template <bool QUAD>
-__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags, int epoch,
+template <bool QUAD, bool FOLD>
+__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags,
                                                           int spin_limit, int* __restrict__ deferred) {
     const int lane = lane_id();
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (gw >= 2 * nw) return;
-    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;   // (uniform over the whole grid)
+    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;   // (the flags were final before this launch began: uniform over the grid)
+    const int epoch = a.epoch;
     const bool even = gw >= nw;
     const int wv = even ? gw - nw : gw;
     WAVE_TS(0);
@@ -2435,7 +2553,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     WAVE_TS(1);
-    solve_wave_poses<QUAD>(a, g, even, wv, lane);
+    solve_wave_poses<QUAD, FOLD>(a, g, even, wv, lane);
     WAVE_TS(2);
     if (!even) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every write-through store of this wave has been acknowledged
@@ -2444,31 +2562,52 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
     }
 }
 
-// The even waves k_solve_m_fused deferred (normally none: every wave returns at once).
+// The fix-up launches behind k_solve_m_fused, one per colour (odd first): the poses a fold-only lane marked in
+// need[] and -- even colour -- the waves that deferred, solved with the complete energy.  Normally nothing is marked
+// and no wave deferred: every wave returns after two scalar loads.
+//   counts[0] += even waves that had deferred, counts[1] += poses solved here because they were marked
 template <bool QUAD>
-__global__ __launch_bounds__(kBlock) void k_solve_m_deferred(SolveArgs a, SolveSeg g, int nw, int* __restrict__ deferred,
-                                                             unsigned long long* __restrict__ n_deferred) {
+__global__ __launch_bounds__(kBlock) void k_solve_m_fix(SolveArgs a, SolveSeg g, int nw, int even, int* __restrict__ deferred,
+                                                        unsigned long long* __restrict__ counts) {
     const int lane = lane_id();
     const int wv = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (wv >= nw) return;
-    if (!deferred[wv]) return;
-    solve_wave_poses<QUAD>(a, g, true, wv, lane);
+    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;
+    const bool wdef = even && deferred[wv] != 0;
+    const bool marks = *a.need_seen == a.epoch;
+    if (!wdef && !marks) return;
+    constexpr int PPW = QUAD ? kWave / 4 : kWave;
+    const int role = QUAD ? (lane & 3) : 0;
+    const int j = wv * PPW + (QUAD ? lane >> 2 : lane);
+    const int tg = seg_pose(g, even != 0, j);
+    bool mine = false;
+    if (tg < g.t1) {
+        mine = wdef || a.need[tg - a.t_begin + 1] == a.epoch;
+        if (mine) {
+            double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
+            double res[3];
+            solve_pose_moments<QUAD, false>(a, tg, prev, res, role);
+            if (role == 0) store_pose(a, tg, res, false);
+        }
+    }
+    const unsigned long long nm = __ballot(mine && role == 0 && !wdef);
     if (lane == 0) {
-        deferred[wv] = 0;
-        atomicAdd(n_deferred, 1ull);
+        if (wdef) {
+            deferred[wv] = 0;
+            atomicAdd(&counts[0], 1ull);
+        }
+        if (nm) atomicAdd(&counts[1], (unsigned long long)__popcll(nm));
     }
 }
 
 // The same half sweep in latency form: one DPP quad (4 lanes) per pose, 16 poses per wave
-// (nelder_mead3_quad).  Chosen by the host when a colour has too few poses to fill the chip.
-__global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, int colour, const int* __restrict__ abort = nullptr) {
-    if (abort && (abort[0] | abort[1] | abort[2])) return;
+// (nelder_mead3_quad).
+__global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, SolveSeg g, int colour) {
+    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;
     const int gid = blockIdx.x * kBlock + threadIdx.x;
-    const int w = gid >> 2, role = gid & 3;
-    int first = a.t_begin > 1 ? a.t_begin : 1;
-    if ((first & 1) != colour) ++first;
-    const int tg = first + 2 * w;
-    if (tg >= a.t_begin + a.nloc) return;  // whole quads leave together
+    const int j = gid >> 2, role = gid & 3;
+    const int tg = seg_pose(g, colour == 0, j);
+    if (tg >= g.t1) return;  // whole quads leave together
     double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
     double res[3];
     solve_pose_moments<true>(a, tg, prev, res, role);

@@ -1,4 +1,4 @@
-"""ctypes binding of the C-ABI in include/icmslam.h (libicmslam_hip.so).
+"""ctypes binding of the C-ABI in include/icmslam.h + include/icmslam_tuning.h (libicmslam_hip.so).
 
 There is no CPU fallback: if the shared library has not been built (or no MI355X is
 present when a solver is created) the import / constructor fails loudly.
@@ -31,7 +31,9 @@ _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)
 _H = C.c_void_p
 
-# name -> (restype, argtypes); every symbol declared in include/icmslam.h
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)   # icm_allgather_fn
+
+# name -> (restype, argtypes); every symbol declared in include/*.h
 SIGNATURES = {
     "icm_create": (C.c_int, [C.POINTER(IcmConfig), C.c_int, C.POINTER(_H)]),
     "icm_destroy": (C.c_int, [_H]),
@@ -46,8 +48,10 @@ SIGNATURES = {
     "icm_get_state": (C.c_int, [_H, _dp, _dp, _dp, _lp]),
     "icm_stats_stride": (C.c_int64, [_H]),
     "icm_bind_exchange": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
-    "icm_bind_exchange_send": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "icm_halo_unpack": (C.c_int, [_H]),
+    "icm_bind_exchange_send": (C.c_int, [_H, C.c_void_p]),
+    "icm_upload_ghost_scan": (C.c_int, [_H, _dp]),
+    "icm_shard_block": (C.c_int64, [C.c_int64, C.c_int]),
+    "icm_comm_init_transport": (C.c_int, [_H, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
     "icm_bind_pose_buffer": (C.c_int, [_H, C.c_void_p]),
     "icm_pose_buffer": (C.c_void_p, [_H]),
     "icm_comm_set_library": (C.c_int, [C.c_char_p]),
@@ -62,6 +66,8 @@ SIGNATURES = {
     "icm_sweep_targets": (C.c_int, [_H]),
     "icm_sweep_solve": (C.c_int, [_H, C.c_int, C.c_int]),
     "icm_sweep_finish": (C.c_int, [_H]),
+    "icm_mark_failed": (C.c_int, [_H, C.c_int]),
+    "icm_failed_rank": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "icm_get_association": (C.c_int, [_H, _ip, _dp, _dp]),
     "icm_get_raw_map": (C.c_int, [_H, _dp, _dp, _lp]),
     "icm_solve_one": (C.c_int, [_H, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp]),
@@ -85,8 +91,9 @@ SIGNATURES = {
     "icm_snapshot_state": (C.c_int, [_H]),
     "icm_restore_state": (C.c_int, [_H]),
     "icm_set_colour_fusion": (C.c_int, [_H, C.c_int]),
-    "icm_set_pipeline": (C.c_int, [_H, C.c_int]),
-    "icm_get_pipeline_used": (C.c_int, [_H]),
+    "icm_set_fold_mode": (C.c_int, [_H, C.c_int]),
+    "icm_get_fixup_poses": (C.c_int, [_H, _lp]),
+    "icm_staging_layout": (C.c_int, [C.c_int64, C.c_int64, _lp]),
     "icm_set_fused_spin_limit": (C.c_int, [_H, C.c_int]),
     "icm_get_fused_deferred": (C.c_int, [_H, _lp]),
     "icm_set_entry_path": (C.c_int, [_H, C.c_int]),

@@ -77,12 +77,20 @@ _PREFILTER_ENGINES = {}
 _SCAN_ENGINES = {}
 
 
+def _config_key(config, device):
+    """Cache key of a helper engine: the VALUES the library is configured with (id() of a config object is recycled
+    after garbage collection, and a config may be edited in place)."""
+    c = make_c_config(config)
+    return (c.deltat, c.Q[0], c.Q[1], c.R[0], c.R[1], c.R[2], c.cte_odom, c.cota, c.dist_thr, c.rango_laser_max, int(c.L),
+            getattr(config, "angle_increment", None), int(device))
+
+
 def actualizar_scan(config, mapa, mapa_referencia, obs, lact, cant_obs_i, device=0):
     """Mapa.actualizar for one scan through the C-ABI (`icm_associate`, reference
     scripts/ICM_SLAM_tools.py:128-201): `mapa` (2,L) float64 C-contiguous and `cant_obs_i` (L) are
     updated IN PLACE, `mapa_referencia` (2,K) is only read.  Returns (labels c (n,) int64, new
     landmarks_actuales)."""
-    key = (id(config), device)
+    key = _config_key(config, device)
     eng = _SCAN_ENGINES.get(key)
     if eng is None:
         eng = _SCAN_ENGINES[key] = SweepEngine(config, device)
@@ -110,7 +118,7 @@ def prefilter_scans(config, scans, device=0):
     if scans.ndim == 1:
         scans = scans[:, None]
     B, n = scans.shape
-    key = (id(config), device)
+    key = _config_key(config, device)
     eng = _PREFILTER_ENGINES.get(key)
     if eng is None:
         eng = _PREFILTER_ENGINES[key] = SweepEngine(config, device)
@@ -172,13 +180,16 @@ class SweepEngine:
             pass
 
     def _chk(self, rc):
+        self.last_rc = rc
         if rc:
             _raise(rc, self.lib.icm_last_error(self.h).decode())
 
     # ---- sequence --------------------------------------------------------------------
-    def upload(self, mediciones, odometria, u, t_begin=0, t_end=None, pose_major=False):
+    def upload(self, mediciones, odometria, u, t_begin=0, t_end=None, pose_major=False, ghost_scan=None):
         """Upload the sequence (or this rank's pose shard of the scans) and run the scan
-        pre-filter once.  `mediciones` is (B,T) like the reference unless pose_major."""
+        pre-filter once.  `mediciones` is (B,T) like the reference unless pose_major.
+        ghost_scan (B,): the scan of pose t_begin - 1 -- ranks > 0 of a pose-sharded job solve that pose too
+        (icm_upload_ghost_scan); taken from `mediciones` itself when that holds the whole sequence."""
         odometria = _f64(odometria)
         u = _f64(u)
         T = odometria.shape[1]
@@ -194,11 +205,18 @@ class SweepEngine:
             if m.shape[1] != T:
                 raise ValueError("mediciones must be (B,T)")
             scans = np.ascontiguousarray(m[:, t_begin:t_end].T)
+            if ghost_scan is None and t_begin >= 2 and t_begin % 2 == 0:
+                ghost_scan = m[:, t_begin - 1]
         if odometria.shape != (3, T) or u.shape != (2, T):
             raise ValueError("odometria must be (3,T) and u (2,T)")
         cosb, sinb, _ = bearing_tables(B, getattr(self.config, "angle_increment", None))
         self._chk(self.lib.icm_upload(self.h, dptr(scans), dptr(odometria), dptr(u), dptr(_f64(cosb)),
                                       dptr(_f64(sinb)), T, B, int(t_begin), t_end))
+        if ghost_scan is not None:
+            g = _f64(np.asarray(ghost_scan, dtype=np.float64).reshape(-1))
+            if g.shape != (B,):
+                raise ValueError("ghost_scan must hold B ranges")
+            self._chk(self.lib.icm_upload_ghost_scan(self.h, dptr(g)))
         nnz = C.c_int64(0)
         self._chk(self.lib.icm_prefilter(self.h, C.byref(nnz)))
         self.T, self.B, self.t_begin, self.nloc, self.nnz = T, B, int(t_begin), t_end - int(t_begin), int(nnz.value)
@@ -274,6 +292,17 @@ class SweepEngine:
     def sweep_targets(self):
         self._chk(self.lib.icm_sweep_targets(self.h))
 
+    def mark_failed(self, code):
+        """This rank's phase A failed with `code` (< 0): put the code into its message so that the other ranks learn
+        of it through the sweep's collective instead of waiting for a rank that left (icm_mark_failed)."""
+        self._chk(self.lib.icm_mark_failed(self.h, int(code)))
+
+    def failed_rank(self):
+        """After the exchange, careful form: (rank, code) of the first rank that failed in phase A, or (-1, 0)."""
+        r, c = C.c_int(-1), C.c_int(0)
+        self._chk(self.lib.icm_failed_rank(self.h, C.byref(r), C.byref(c)))
+        return int(r.value), int(c.value)
+
     def sweep_solve(self, schedule="redblack", colour=-1):
         self._chk(self.lib.icm_sweep_solve(self.h, SCHEDULES[schedule], int(colour)))
 
@@ -306,12 +335,8 @@ class SweepEngine:
     def bind_exchange(self, stats_ptr, rank, world):
         self._chk(self.lib.icm_bind_exchange(self.h, C.c_void_p(stats_ptr), int(rank), int(world)))
 
-    def bind_exchange_send(self, stats_send_ptr, halo_send_ptr, halo_all_ptr):
-        self._chk(self.lib.icm_bind_exchange_send(self.h, C.c_void_p(stats_send_ptr), C.c_void_p(halo_send_ptr),
-                                                  C.c_void_p(halo_all_ptr)))
-
-    def halo_unpack(self):
-        self._chk(self.lib.icm_halo_unpack(self.h))
+    def bind_exchange_send(self, stats_send_ptr):
+        self._chk(self.lib.icm_bind_exchange_send(self.h, C.c_void_p(stats_send_ptr)))
 
     def set_stream(self, stream_ptr):
         self._chk(self.lib.icm_set_stream(self.h, C.c_void_p(stream_ptr)))
@@ -347,6 +372,21 @@ class SweepEngine:
         self._torch_before_rccl()
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
         self._chk(self.lib.icm_comm_init(self.h, C.cast(buf, C.c_void_p), int(rank), int(world)))
+
+    def comm_init_transport(self, rank, world, all_gather):
+        """The library's sharded driver over a caller-supplied all-gather: all_gather(send_ptr, recv_ptr, count, stream_ptr)
+        gathers `count` doubles of device memory from every rank (icm_comm_init_transport); exceptions become a failed
+        sweep."""
+        def tramp(send, recv, count, stream, user):
+            try:
+                all_gather(send, recv, int(count), stream)
+                return 0
+            except Exception:   # noqa: BLE001 (nothing may propagate through the C frames)
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._transport_cb = _lib.ALLGATHER_FN(tramp)     # keep the trampoline alive as long as the handle
+        self._chk(self.lib.icm_comm_init_transport(self.h, int(rank), int(world), self._transport_cb, None))
 
     def comm_destroy(self):
         self._chk(self.lib.icm_comm_destroy(self.h))
@@ -427,14 +467,16 @@ class SweepEngine:
         """True (default): both colours of an unsharded red-black sweep in one launch."""
         self._chk(self.lib.icm_set_colour_fusion(self.h, int(bool(on))))
 
-    def set_pipeline(self, on):
-        """True: unsharded red-black sweeps run as two time segments pipelined over two streams (default
-        False: measured slower on MI355X, kept as a tested option)."""
-        self._chk(self.lib.icm_set_pipeline(self.h, int(bool(on))))
+    def set_fold_mode(self, mode):
+        """-1 automatic, 1 the one-launch solve evaluates the folded energy only and leaves poses outside its range to
+        the fix-up launches, 0 the complete energy in the main kernel (icm_set_fold_mode)."""
+        self._chk(self.lib.icm_set_fold_mode(self.h, int(mode)))
 
-    def pipeline_used(self):
-        """Did the last sweep run pipelined?"""
-        return self.lib.icm_get_pipeline_used(self.h) == 1
+    def fixup_poses(self):
+        """Poses the fix-up launches solved because a fold-only lane marked them, so far."""
+        n = C.c_int64(0)
+        self._chk(self.lib.icm_get_fixup_poses(self.h, C.byref(n)))
+        return int(n.value)
 
     def set_fused_spin_limit(self, polls):
         """Polls an even wave of the one-launch solve waits before deferring to the fix-up launch."""

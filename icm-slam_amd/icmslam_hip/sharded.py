@@ -1,53 +1,65 @@
-"""Pose-sharded ICM sweep: one process per GPU, torch.distributed (backend "nccl" = RCCL over
-xGMI) for the two exchanges a sweep needs.
+"""Pose-sharded ICM sweep: one process per GPU, ONE collective per sweep (torch.distributed, backend
+"nccl" = RCCL over xGMI; or the C library's own RCCL call, `LibrarySweep`).
 
-Partition: contiguous pose blocks of `blk = ceil(T / world)` poses; rank r owns poses
-[r*blk, min((r+1)*blk, T)) -- every rank must own at least one pose (icm_upload refuses an empty
-shard).  Scans live only on their owner; odometry, velocities, the pose
-array and the landmark table are replicated (they are KB..MB).
+Partition: contiguous pose blocks of `blk` = ceil(T / world) rounded up to an EVEN number of poses
+(`icm_shard_block`); rank r owns [r*blk, min((r+1)*blk, T)) -- every rank must own at least one pose
+(icm_upload refuses an empty shard).  Scans live only on their owner, plus ONE extra scan per rank > 0:
+that of the pose in front of its block, the rank's *ghost pose*.  Odometry, velocities, the pose array
+and the landmark table are replicated (they are KB..MB).
 
-Per sweep:
+Per sweep (the loop being sharded is scripts/ICM_ROS.py:141-158):
   1. local phase A and per-landmark sufficient statistics (sum x, sum y, n)  [no comm]
-  2. ONE all-gather of the [3L+8] statistics: every rank gets the total (new map) and the
-     exclusive prefix over lower ranks (state of each running mean at its first pose)
-  3. targets, then the odd poses of the shard                                 [no comm]
-  4. halo exchange: a solve reads only the poses t-1 and t+1, so a shard needs one pose from
-     each neighbour -- every rank contributes its first and last pose (48 B) to one tiny
-     all-gather and copies the two it needs next to its block
-  5. the even poses; their boundary values travel in the header of the NEXT sweep's statistics
-     message (step 2), so a sweep costs two collectives
-  6. Mapa.filtrar, replicated (deterministic) on every rank
+  2. ONE all-gather of the [3L+16] message of every rank: the statistics give every rank the total
+     (new map) and the exclusive prefix over lower ranks (state of each running mean at its first
+     pose); the 16-double header carries the rank's new-landmark count, its overflow flags and its
+     first / last / last-but-one pose as the PREVIOUS sweep left them -- the old values the
+     neighbours' boundary solves read
+  3. targets; the ghost pose's entries and moments                            [no comm]
+  4. both colours of the shard in ONE launch.  A red-black sweep solves the odd poses from old even
+     neighbours, then the even poses from new odd neighbours; shards start at even poses, so the only
+     value a shard would need from another rank in mid-sweep is the new value of the odd pose in front
+     of it -- and that one it computes itself, from the same beams, targets and neighbour values as
+     its owner (the ghost pose).  No halo exchange.
+  5. Mapa.filtrar, replicated (deterministic) on every rank
 
-The pose blocks themselves are gathered only when the caller asks for the state
-(`get_state`), not per sweep.  The payloads are tiny (240 KB of statistics per rank at
-L = 10k, 48 B of halo), so the collectives are latency-bound; xGMI link bandwidth is
-irrelevant here.
+The pose blocks themselves are gathered only when the caller asks for the state (`get_state`), not
+per sweep.  The payload is tiny (240 KB per rank at L = 10k), so the collective is latency-bound;
+xGMI link bandwidth is irrelevant here.
 """
 import numpy as np
 
 
-def partition(T, world):
+def shard_block(T, world):
+    """Poses per rank: ceil(T / world) rounded up to an even number (include/icmslam.h icm_shard_block)."""
     blk = (T + world - 1) // world
+    return blk + (blk & 1)
+
+
+def partition(T, world):
+    blk = shard_block(T, world)
     return blk, [(min(r * blk, T), min((r + 1) * blk, T)) for r in range(world)]
+
+
+def ghost_scan(scans_pose_major_full, a):
+    """The scan a rank whose block starts at pose `a` uploads beside its own: pose a - 1 (None for rank 0)."""
+    return None if a < 2 else scans_pose_major_full[a - 1]
 
 
 class ShardedSweep:
     """Drives one rank.  `engine` is a SweepEngine (or anything with the same phase API);
-    `comm` does the collectives: TorchComm (torch.distributed) or NoComm (ranks that share
-    the exchange buffers inside one process)."""
+    `comm` does the collective: TorchComm (torch.distributed) or NoComm (ranks that share
+    the statistics buffer inside one process; their pose arrays stay private, like real replicas)."""
 
-    def __init__(self, engine, rank, world, T, comm=None, buffers=None):
+    def __init__(self, engine, rank, world, T, comm=None, stats=None):
         import torch
         self.torch = torch
         self.eng, self.rank, self.world, self.T = engine, rank, world, T
         self.blk, self.parts = partition(T, world)
         self.stride = engine.stats_stride()
         dev = getattr(engine, "exchange_device", "cuda")
-        if buffers is None:
+        if stats is None:
             stats = torch.zeros(world * self.stride, dtype=torch.float64, device=dev)
-            poses = torch.zeros(world * self.blk * 3, dtype=torch.float64, device=dev)
-        else:
-            stats, poses = buffers
+        poses = torch.zeros(world * self.blk * 3, dtype=torch.float64, device=dev)
         self.stats, self.poses = stats, poses
         self.comm = comm if comm is not None else TorchComm()
         self.native = False
@@ -59,33 +71,12 @@ class ShardedSweep:
             engine.bind_exchange(stats.data_ptr(), rank, world)
             engine.bind_pose_buffer(poses.data_ptr())
             if not isinstance(self.comm, NoComm):
-                # real collectives: the library writes the send-side buffers (its statistics; its
-                # first and last pose after every half sweep) and unpacks the neighbours' poses,
-                # so that each exchange is one collective call and one C call
+                # a real collective: the library writes its message into a send buffer, so that the exchange
+                # is one collective call and nothing else (all-gather input and output must not alias)
                 self.stats_send = torch.zeros(self.stride, dtype=torch.float64, device=dev)
-                self.halo_send = torch.zeros(6, dtype=torch.float64, device=dev)
-                self.halo_recv = torch.zeros(world * 6, dtype=torch.float64, device=dev)
-                engine.bind_exchange_send(self.stats_send.data_ptr(), self.halo_send.data_ptr(), self.halo_recv.data_ptr())
+                engine.bind_exchange_send(self.stats_send.data_ptr())
                 self.native = True
-        # halo bookkeeping: rows (first pose, last pose) of every rank; which of them this rank
-        # needs (the last pose of the rank below, the first pose of the rank above; only trailing
-        # ranks can be empty, and an empty rank needs nothing)
-        a, b = self.parts[rank]
-        self.own = (a, b)
-        P = self.poses.view(-1, 3)
-        idev = P.device
-        self.halo_all = torch.zeros(world * 2, 3, dtype=torch.float64, device=idev)
-        last = max(b - 1, a) if b > a else 0
-        self.edge_idx = torch.tensor([a if b > a else 0, last], dtype=torch.long, device=idev)
-        src, dst = [], []
-        if b > a and a > 0:
-            src.append(2 * (rank - 1) + 1)
-            dst.append(a - 1)
-        if b > a and b < T:
-            src.append(2 * (rank + 1))
-            dst.append(b)
-        self.halo_src = torch.tensor(src, dtype=torch.long, device=idev)
-        self.halo_dst = torch.tensor(dst, dtype=torch.long, device=idev)
+        self.own = self.parts[rank]
 
     def set_state(self, mapa_viejo, x, x0, lact=None):
         self.eng.set_state(mapa_viejo, x, x0, lact)
@@ -98,21 +89,30 @@ class ShardedSweep:
         # strong-scaled job that round trip is a quarter of the sweep).  Every rank's flags travel in the header of its
         # statistics, so if ANY rank's tables overflowed all ranks leave their state alone, all see it at the end, and
         # all repeat the sweep the careful way.
-        can = hasattr(e, "set_optimistic") and not isinstance(self.comm, NoComm)   # (shared buffers: see run_virtual_ranks)
+        can = callable(getattr(e, "set_optimistic", None)) and not isinstance(self.comm, NoComm)   # (shared buffers: see run_virtual_ranks)
         for attempt in (0, 1):
             if can:
                 e.set_optimistic(attempt == 0)
-            e.sweep_local()
-            self.comm.gather_stats(self)
+            # a rank whose phase A fails on its own (careful form: labels beyond L, a table too small at its largest
+            # size) still sends its message, with the error code in the header: every rank fails together
+            err = None
+            try:
+                e.sweep_local()
+            except (IndexError, RuntimeError) as ex:
+                if not hasattr(e, "mark_failed") or getattr(e, "last_rc", 0) >= 0:
+                    raise
+                err = ex
+                e.mark_failed(e.last_rc)
+            self.comm.gather_stats(self)            # the sweep's one collective
+            if hasattr(e, "failed_rank") and (err is not None or attempt == 1 or not can):
+                fr, code = e.failed_rank()
+                if err is not None:
+                    raise err
+                if fr >= 0:
+                    from .engine import _raise
+                    _raise(code, "sharded sweep: rank %d failed in phase A" % fr)
             e.sweep_targets()
-            if self.world == 1:        # no neighbour, no halo: both colours in the one-launch solve
-                e.sweep_solve("redblack", -1)
-            else:
-                e.sweep_solve("redblack", 1)
-                self.comm.halo(self)
-                e.sweep_solve("redblack", 0)
-                if not self.native:      # (native: the even poses' boundary values ride in the next statistics message)
-                    self.comm.halo(self)
+            e.sweep_solve("redblack", -1)           # both colours, ghost pose included, one launch
             if not e.sweep_finish():
                 break
         if can:
@@ -125,16 +125,21 @@ class ShardedSweep:
 
 
 class LibrarySweep:
-    """One rank of a pose-sharded sweep whose collectives the C library issues itself (RCCL
+    """One rank of a pose-sharded sweep whose collective the C library issues itself (RCCL
     `ncclAllGather` on the handle's stream: `icm_comm_init` / `icm_sweep_sharded`, include/icmslam.h) --
     a sweep is ONE C call, nothing of it runs through Python or torch.distributed.  The 128-byte
     communicator id travels once, by `bcast(bytes_or_None) -> bytes` (rank 0 passes the id, the others
-    None); default: a broadcast on the default torch.distributed group, whatever its backend."""
+    None); default: a broadcast on the default torch.distributed group, whatever its backend.
+    `transport(send_ptr, recv_ptr, count, stream_ptr)`: carry the all-gathers yourself instead of RCCL
+    (`icm_comm_init_transport`: MPI, a test harness hopping through host memory, ...)."""
 
-    def __init__(self, engine, rank, world, T, bcast=None):
+    def __init__(self, engine, rank, world, T, bcast=None, transport=None):
         self.eng, self.rank, self.world, self.T = engine, rank, world, T
         self.blk, self.parts = partition(T, world)
         self.own = self.parts[rank]
+        if transport is not None:
+            engine.comm_init_transport(rank, world, transport)
+            return
         if bcast is None:
             bcast = _torch_bcast
         uid = bcast(engine.comm_unique_id() if rank == 0 else None)
@@ -184,21 +189,10 @@ class TorchComm:
         else:
             self.all_gather(sw.stats, sw.rank, sw.stride)
 
-    def halo(self, sw):
-        if sw.native:   # packed by icm_sweep_solve, unpacked by icm_halo_unpack
-            self.dist.all_gather_into_tensor(sw.halo_recv, sw.halo_send, group=self.group)
-            sw.eng.halo_unpack()
-            return
-        P = sw.poses.view(-1, 3)
-        edges = P.index_select(0, sw.edge_idx)                       # (2,3): my first and last pose
-        self.dist.all_gather_into_tensor(sw.halo_all, edges, group=self.group)
-        if sw.halo_dst.numel():
-            P.index_copy_(0, sw.halo_dst, sw.halo_all.index_select(0, sw.halo_src))
-
 
 class NoComm:
-    """Ranks living in one process on one GPU and bound to the SAME buffers: every rank's
-    slot is already visible to the others."""
+    """Ranks living in one process on one GPU and bound to the SAME statistics buffer: every rank's
+    message is already visible to the others (run_virtual_ranks orders the phases)."""
 
     def all_gather(self, buf, rank, count):
         pass
@@ -206,22 +200,32 @@ class NoComm:
     def gather_stats(self, sw):
         pass
 
-    def halo(self, sw):
-        pass
 
-
-def run_virtual_ranks(engines, sweeps, schedule="redblack"):
-    """Lock-step execution of several in-process ranks (one GPU, shared buffers): the exact
-    phase order of ShardedSweep.sweep with the collectives replaced by shared memory."""
-    # (always the careful form: ranks that share buffers inside one process are ordered by the host's look at phase A
+def run_virtual_ranks(runs, sweeps, schedule="redblack"):
+    """Lock-step execution of several in-process ranks (`runs`: their ShardedSweep objects, built with
+    comm=NoComm() and the same `stats` tensor): the exact phase order of ShardedSweep.sweep with the
+    collective replaced by shared memory.  Each rank keeps its own pose array, like a real replica;
+    at the end every rank's block is copied into every other rank's array (the pose all-gather of
+    get_state)."""
+    # (always the careful form: ranks that share a buffer inside one process are ordered by the host's look at phase A
     # in the middle of the sweep -- a sweep queued whole relies on the collective for that)
+    engines = [r.eng for r in runs]
+    torch = runs[0].torch
     for _ in range(sweeps):
         for e in engines:
             e.sweep_local()
+        torch.cuda.synchronize()       # every rank's message is in the shared buffer
         for e in engines:
             e.sweep_targets()
-        for colour in (1, 0):
-            for e in engines:
-                e.sweep_solve(schedule, colour)
+        for e in engines:
+            e.sweep_solve(schedule, -1)
         for e in engines:
             e.sweep_finish()
+    torch.cuda.synchronize()
+    n = runs[0].blk * 3
+    for src in runs:
+        blk = src.poses[src.rank * n:(src.rank + 1) * n]
+        for dst in runs:
+            if dst is not src:
+                dst.poses[src.rank * n:(src.rank + 1) * n].copy_(blk)
+    torch.cuda.synchronize()

@@ -90,10 +90,26 @@ def _grid_index(pts, cell):
     return dict(x0=x0, y0=y0, nx=nx, ny=ny, cell=cell, order=order, start=start)
 
 
-def raycast(poses, lm, B, inc, rng, noise=0.01, chunk=2048):
+NOISE_BLOCK = 256   # poses per block of the range-noise stream
+
+
+def range_noise(seed, t_begin, t_end, B, sigma):
+    """Gaussian range noise of the poses [t_begin, t_end), (P,B): a counter-based stream keyed by
+    (seed, block of NOISE_BLOCK poses), so that a pose's scan carries the same noise whichever
+    rank of whatever partition generates it (an N-rank job sweeps the N = 1 job's inputs)."""
+    out = np.empty((t_end - t_begin, B))
+    for b in range(t_begin // NOISE_BLOCK, (max(t_end, t_begin + 1) - 1) // NOISE_BLOCK + 1):
+        blk = np.random.default_rng([seed, 0x5CA9, b]).normal(0.0, sigma, size=(NOISE_BLOCK, B))
+        a0, a1 = max(b * NOISE_BLOCK, t_begin), min((b + 1) * NOISE_BLOCK, t_end)
+        if a1 > a0:
+            out[a0 - t_begin:a1 - t_begin] = blk[a0 - b * NOISE_BLOCK:a1 - b * NOISE_BLOCK]
+    return out
+
+
+def raycast(poses, lm, B, inc, noise, chunk=2048):
     """Ranges (P,B) to the trunk surfaces (no hit = RMAX), beam k at bearing k*inc in the
     sensor frame, sensor x-axis to the robot's right (world bearing = ang + theta - pi/2,
-    reference scripts/ICM_ROS.py:191)."""
+    reference scripts/ICM_ROS.py:191).  `noise` (P,B) is added to the beams that hit."""
     P = poses.shape[1]
     out = np.full((P, B), RMAX)
     gi = _grid_index(lm, 4.0)
@@ -155,7 +171,7 @@ def raycast(poses, lm, B, inc, rng, noise=0.01, chunk=2048):
         flat = pi[pair][okb] * B + kmod[okb]
         np.minimum.at(out[p0:p1].reshape(-1), flat, rng_hit[okb])
     hit = out < RMAX
-    out[hit] += rng.normal(0.0, noise, size=int(hit.sum()))
+    out[hit] += noise[hit]
     np.clip(out, 0.05, RMAX, out=out)
     return out
 
@@ -188,10 +204,14 @@ def make_workload(T, K, B, seed=20181, t_begin=0, t_end=None, L_margin=4096):
     map_init = lm + rng.normal(0, 0.05, lm.shape)
     inc = 2 * np.pi / B
     angle_increment = None if B == 360 else inc  # 360 rows = the reference's own 1 degree
-    shard_rng = np.random.default_rng([seed, t_begin, t_end])
-    z = raycast(x_true[:, t_begin:t_end], lm, B, inc, shard_rng)
+    z = raycast(x_true[:, t_begin:t_end], lm, B, inc, range_noise(seed, t_begin, t_end, B, 0.01))
     zz = np.minimum(z + RADIO, RMAX)
     wl = Workload()
+    # the scan in front of the shard: ranks > 0 of a sharded job solve that pose too (their ghost pose)
+    wl.ghost_scan = None
+    if t_begin >= 1:
+        zg = raycast(x_true[:, t_begin - 1:t_begin], lm, B, inc, range_noise(seed, t_begin - 1, t_begin, B, 0.01))
+        wl.ghost_scan = np.minimum(zg + RADIO, RMAX)[0]
     wl.T, wl.K, wl.B, wl.t_begin, wl.t_end = T, K, B, t_begin, t_end
     wl.map_true, wl.map_init, wl.x_true, wl.x_init = lm, map_init, x_true, x_init
     wl.u, wl.odometry, wl.scans = u, odo, zz

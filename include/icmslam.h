@@ -18,6 +18,7 @@
 #ifndef ICMSLAM_H
 #define ICMSLAM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -74,6 +75,12 @@ int icm_set_stream(icm_handle *h, void *hip_stream);
 int icm_upload(icm_handle *h, const double *ranges, const double *odo, const double *u,
                const double *cosb, const double *sinb, int64_t T, int64_t B, int64_t t_begin,
                int64_t t_end);
+/* Multi-rank jobs, ranks > 0 only (between icm_upload and icm_prefilter): the scan of pose t_begin - 1, the last pose
+ * of the shard below.  A shard solves that pose as well (its "ghost pose": same beams, same targets, same
+ * neighbours' values as its owner uses), so that the shard's first even pose finds its odd neighbour without an exchange
+ * between the two colours of a sweep (reference loop scripts/ICM_ROS.py:141-158; a pose reads t-1 and t+1 only, :211-214).
+ *   ranges_row [B] */
+int icm_upload_ghost_scan(icm_handle *h, const double *ranges_row);
 /* filtrar_z for every scan of the shard, once per sequence (reference
  * scripts/ICM_SLAM_tools.py:22-58, called per pose per sweep at scripts/ICM_ROS.py:130,142).
  * nnz_out = number of kept beams. */
@@ -113,31 +120,29 @@ int icm_get_state(icm_handle *h, double *x, double *map_out, double *counts_out,
 int icm_snapshot_state(icm_handle *h);
 int icm_restore_state(icm_handle *h);
 
-/* ---- sharded sweep: the same sweep cut at the one point where ranks exchange data ------ */
-/* Bind the exchange buffers (device memory owned by the caller, e.g. torch tensors):
- *   stats_all [world * icm_stats_stride()] doubles: rank r's landmark sufficient
- *             statistics live at stats_all + r*stride; the caller all-gathers it (RCCL)
- *             between icm_sweep_local() and icm_sweep_solve().
- * The pose array is replicated; the caller all-gathers the shard blocks after each colour
- * (see icm_bind_pose_buffer). */
+/* ---- sharded sweep: the same sweep cut at the ONE point where ranks exchange data -------- */
+/* Partition: contiguous pose blocks of icm_shard_block(T, world) poses -- ceil(T / world) rounded up to an
+ * even number, so every shard starts at an even pose; rank r owns [r blk, min((r+1) blk, T)) and uploads exactly those
+ * scans plus, for r > 0, the scan in front (icm_upload_ghost_scan).  odo / u / the pose array / the landmark table are
+ * replicated.  One sweep of the reference loop scripts/ICM_ROS.py:141-158, red-black order, is then per rank
+ *     icm_sweep_local    phase A over the shard + its landmark sufficient statistics
+ *     ONE all-gather     of icm_stats_stride() doubles per rank: [sum x (L) | sum y (L) | n (L) | header (16)], header =
+ *                        [0] landmarks created, [1] flags / error code, [2..4] first pose, [5..7] last pose, [8..10] last
+ *                        pose but one of the shard -- the previous sweep's values, which the neighbours need as OLD values
+ *     icm_sweep_targets  prefix over lower ranks -> running-mean targets, raw map; the neighbours' boundary poses are
+ *                        unpacked from their headers; the ghost pose's entries and moments
+ *     icm_sweep_solve(REDBLACK, -1)   both colours of the shard in one launch (the ghost pose is its first odd pose)
+ *     icm_sweep_finish   Mapa.filtrar, replicated
+ * -- no second exchange.  Bind the exchange buffers (device memory owned by the caller, e.g. torch tensors):
+ *   stats_all [world * icm_stats_stride()] doubles: rank r's message lives at stats_all + r*stride; the caller
+ *             all-gathers it between icm_sweep_local() and icm_sweep_targets(). */
+int64_t icm_shard_block(int64_t T, int world);
 int64_t icm_stats_stride(const icm_handle *h);
 int icm_bind_exchange(icm_handle *h, void *stats_all_dev, int rank, int world);
-/* Optional send-side buffers, so that each exchange is ONE collective call and nothing else
- * on the caller's side (all-gather input and output must not alias):
- *   stats_send [icm_stats_stride()] doubles: icm_sweep_local() writes this rank's statistics
- *              here (instead of into its slice of stats_all); the caller all-gathers
- *              stats_send -> stats_all.
- *   halo_send [6] doubles: after every icm_sweep_solve() the first and the last pose of the
- *              shard, (x, y, theta) each; the caller all-gathers halo_send -> halo_all
- *              [world * 6] and calls icm_halo_unpack(), which copies the last pose of rank-1
- *              and the first pose of rank+1 next to the shard in the pose buffer (a solve
- *              reads only poses t-1 and t+1, scripts/ICM_ROS.py:211-214).  With halo buffers
- *              bound, the statistics message also carries the shard's boundary poses in its
- *              header and icm_sweep_targets() unpacks them, so a sweep needs the halo
- *              exchange only between its two half sweeps.
- * Any pointer may be null (that exchange then works in place as described above). */
-int icm_bind_exchange_send(icm_handle *h, void *stats_send_dev, void *halo_send_dev, void *halo_all_dev);
-int icm_halo_unpack(icm_handle *h);
+/* Optional send-side buffer, so that the exchange is one collective call and nothing else on the caller's side
+ * (all-gather input and output must not alias): stats_send [icm_stats_stride()] doubles -- icm_sweep_local() writes this
+ * rank's message here instead of into its slice of stats_all.  Null = in place. */
+int icm_bind_exchange_send(icm_handle *h, void *stats_send_dev);
 /* Use caller-owned device memory for the poses: (T,3) doubles, pose-major (a contiguous
  * block of poses is a contiguous block of memory, so shards all-gather in place).  Call
  * before icm_set_state. */
@@ -145,17 +150,21 @@ int icm_bind_pose_buffer(icm_handle *h, void *x_dev);
 void *icm_pose_buffer(icm_handle *h);                 /* device pointer of x (T,3)          */
 /* Collectives issued by the library itself (RCCL over xGMI, resolved with dlopen at run time)
  * instead of by the caller: rank 0 makes an id (icm_comm_unique_id, 128 bytes) and hands it to every
- * rank by whatever means the application has; each rank, after uploading block `rank` of
- * ceil(T / world)-pose blocks, calls icm_comm_init, which creates the communicator and allocates and
- * binds the exchange buffers (statistics, halos, replicated pose array).  icm_sweep_sharded then is
- * one whole red-black sweep -- phase A, all-gather of the statistics, targets, odd poses, all-gather
- * of the halos, even poses, Mapa.filtrar -- with both collectives on the handle's stream;
- * icm_gather_poses all-gathers the pose blocks before icm_get_state. */
+ * rank by whatever means the application has; each rank, after uploading block `rank`, calls icm_comm_init, which
+ * creates the communicator and allocates and binds the exchange buffers (statistics, replicated pose array).
+ * icm_sweep_sharded then is one whole red-black sweep as listed above with its one ncclAllGather on the handle's stream;
+ * a rank that fails on its own in phase A still takes part in the collective and every rank returns that error.
+ * icm_gather_poses all-gathers the pose blocks (in place) before icm_get_state. */
 int icm_comm_set_library(const char *path);           /* the RCCL copy to load if the process has none loaded yet
                                                           (a process must use ONE: e.g. the copy a PyTorch wheel bundles) */
 int icm_comm_available(void);                         /* 1 when an RCCL library can be resolved */
 int icm_comm_unique_id(void *id128);
 int icm_comm_init(icm_handle *h, const void *id128, int rank, int world);
+/* The same driver over a caller-supplied all-gather instead of RCCL (MPI, a test harness that carries the messages
+ * through host memory): gather `count` doubles from every rank's `send_dev` into `recv_dev` (rank-major; send_dev may be
+ * recv_dev + rank*count), ordered after the work queued on `hip_stream`, complete or stream-ordered on return; 0 = ok. */
+typedef int (*icm_allgather_fn)(const void *send_dev, void *recv_dev, size_t count, void *hip_stream, void *user);
+int icm_comm_init_transport(icm_handle *h, int rank, int world, icm_allgather_fn fn, void *user);
 int icm_comm_destroy(icm_handle *h);
 int icm_sweep_sharded(icm_handle *h);
 int icm_gather_poses(icm_handle *h);
@@ -170,6 +179,13 @@ int icm_sweep_targets(icm_handle *h);                 /* prefix over ranks -> ta
 int icm_sweep_solve(icm_handle *h, int schedule, int colour); /* colour 1 = odd, 0 = even,  */
                                                       /* -1 = both / sequential             */
 int icm_sweep_finish(icm_handle *h);                  /* Mapa.filtrar, next mapa_viejo       */
+/* Failing together.  A rank whose icm_sweep_local failed in the careful form (a table too small even at its largest
+ * size, labels beyond L: the reference's IndexError, scripts/ICM_SLAM_tools.py:191) must not leave the others waiting in
+ * the collective: it calls icm_mark_failed(h, code) -- its message then carries the code in header [1] -- and takes
+ * part in the exchange; after it, EVERY rank calls icm_failed_rank and stops if some rank failed (*rank_out >= 0,
+ * *code_out its ICM_ERR_* code).  icm_sweep_sharded does both itself. */
+int icm_mark_failed(icm_handle *h, int code);
+int icm_failed_rank(icm_handle *h, int *rank_out, int *code_out);
 
 /* ---- kernel-level entry points for parity tests ---------------------------------------- */
 /* Labels of every kept beam after phase A of the last sweep (reference `c` of
@@ -210,80 +226,6 @@ int icm_init_pass(icm_handle *h, const double *x0, double *y, double *counts, in
 int icm_filtrar(const icm_config *cfg, const double *y, const double *counts, int64_t lact,
                 double *y_out, double *counts_out, int64_t *lact_out);
 
-/* Test hook: run phase A with the brute-force kernel (every beam against every landmark of
- * mapa_viejo, table tiled through LDS) instead of the grid search.  Same results. */
-int icm_set_brute_force(icm_handle *h, int on);
-
-/* Keep the per-beam outputs of a sweep (label and running-mean target of every kept beam)
- * for icm_get_association; off by default (they cost 28 B of HBM traffic per kept beam). */
-int icm_set_debug(icm_handle *h, int on);
-/* With debug on: per pose (T,3) row-major [final energy, NM iterations, function evaluations]
- * of the last sweep's solve (0 for poses without a solve). */
-int icm_get_solve_diag(icm_handle *h, double *out);
-/* Form in which the pose solves evaluate the observation energy h(x) of
- * scripts/ICM_ROS.py:171-200 -- the same function in three algebraically identical forms:
- *   0 (default) moment form: quadratic form in (dp, cos d - 1, sin d) about the pose's
- *               previous value, 14 sums per pose; one LANE solves a pose
- *   1           one term per kept beam, literally the reference's sum; one wave per pose
- *   2           one term per (pose, landmark) entry: k |p + R bbar - y|^2_Q + scatter; one
- *               wave per pose
- * Forms 1 and 2 exist to cross-check form 0. */
-int icm_set_energy_form(icm_handle *h, int form);
-
-/* Lanes per pose in the red-black solves: 0 = one lane per pose (throughput form), 1 = one DPP
- * quad per pose evaluating the four candidate points of a Nelder-Mead iteration at once (latency
- * form, for colours with fewer poses than the chip has lanes), -1 = automatic (default).
- * Bit-identical results. */
-int icm_set_solve_lanes(icm_handle *h, int mode);
-
-/* Unsharded red-black sweeps in throughput form: 1 (default) = both colours in ONE launch, every
- * even wave starting as soon as the two odd waves holding its poses' neighbours are done
- * (k_solve_m_fused); 0 = one launch per colour.  Bit-identical results. */
-int icm_set_colour_fusion(icm_handle *h, int on);
-/* Unsharded red-black sweeps on the device-resident state (icm_sweep_device / icm_sweep): 1 =
- * software-pipelined over two HIP streams -- the sequence is cut at an even pose into
- * two time segments, and the pose solves of one segment (bounded by their serial Nelder-Mead
- * chains) run beside the association / running-mean kernels of the other (bounded by vector
- * issue); 0 (default) = one segment, one stream.  Same kernels and arithmetic per pose:
- * bit-identical results.  Measured on MI355X the pipelined form is SLOWER (0.71 vs 0.62 ms per S2
- * sweep: both halves are vector-issue hungry, so side by side each runs 1.4-1.6x longer), which is
- * why it is off by default; it stays as a tested option.  Falls back to 0 by itself for short sequences, the sort-based entry pipeline, debug
- * dumps, per-kernel timing and after a table overflow.  icm_get_pipeline_used: the last sweep. */
-int icm_set_pipeline(icm_handle *h, int on);
-int icm_get_pipeline_used(const icm_handle *h);
-
-/* How many times an even wave of the one-launch solve polls for its odd neighbours (~0.2 us per
- * poll; default 1 << 17) before it DEFERS: it leaves its poses untouched and the fix-up launch
- * queued right behind (k_solve_m_deferred) solves them after the kernel boundary.  Forward
- * progress therefore never depends on the order workgroups are dispatched in; 0 defers every wave
- * whose neighbours are not done at its first look (= one launch per colour, through the same
- * code).  Bit-identical results for every value.  icm_get_fused_deferred: waves deferred so far
- * over the handle's life (synchronises the stream). */
-int icm_set_fused_spin_limit(icm_handle *h, int polls);
-int icm_get_fused_deferred(icm_handle *h, int64_t *waves);
-
-/* Pipeline that turns the per-pose entries into running-mean targets (the time-ordered
- * per-landmark prefix of Mapa.actualizar, scripts/ICM_SLAM_tools.py:184-196):
- *   1 / -1 (default) = hierarchical running sums (pose chunks -> superchunks -> per-landmark
- *       column prefix; no sort); used for the moment-form solves.  A map so dense that a
- *       64-pose chunk sees more than ~190 distinct landmarks makes the sweep fall back to
- *   0 = the sort-based pipeline (radix sort of the entries by landmark + one wave per
- *       landmark), which has no such limit and also serves energy forms 1/2 and icm_set_debug.
- * The two differ only in the order the per-landmark sums are added up (~1e-15 relative).
- * icm_get_entry_path: pipeline the last sweep actually ran (0 or 1). */
-int icm_set_entry_path(icm_handle *h, int mode);
-int icm_get_entry_path(const icm_handle *h);
-
-/* Where Mapa.filtrar runs inside a sweep: 1 (default) = on the GPU (the k_fl_* kernel chain on a
- * side stream: prune, grid, nearest-neighbour pairs, and -- when survivors are closer than dist_thr
- * -- label propagation, renumbering and count-weighted means; only coincident landmarks, an empty
- * map or a merge component of more than 7 landmarks go to the host routine), 0 = always the host
- * routine icm_filtrar.  Same results.
- * icm_last_filtrar_info: [0] landmarks_actuales after the last sweep's filter, [1] where it ran
- * (0 GPU, no merges; 1 GPU with merges; 2 host routine), [2] landmarks that had a neighbour closer
- * than dist_thr (-1 on the host path). */
-int icm_set_gpu_filtrar(icm_handle *h, int on);
-int icm_last_filtrar_info(const icm_handle *h, int64_t *out3);
 /* Mapa.filtrar (scripts/ICM_SLAM_tools.py:204-265) on the GPU for a caller-held map: same
  * arguments as icm_filtrar; *path_out as [1] above.  Invalidates the handle's sweep state
  * (icm_set_state again before the next sweep). */

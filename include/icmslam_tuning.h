@@ -1,0 +1,100 @@
+/*
+ * icmslam_tuning.h -- cross-check forms, test hooks and tuning knobs of the MI355X-native ICM sweep.
+ *
+ * Nothing here is needed to drive a sweep (include/icmslam.h is the drop-in boundary): these entry points select
+ * algebraically identical forms of the same computation for parity tests, expose counters, or switch experiments
+ * measured in DESIGN.md.  Every one of them leaves the results bit-identical unless it says otherwise.
+ */
+#ifndef ICMSLAM_TUNING_H
+#define ICMSLAM_TUNING_H
+
+#include "icmslam.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook: run phase A with the brute-force kernel (every beam against every landmark of
+ * mapa_viejo, table tiled through LDS) instead of the grid search.  Same results. */
+int icm_set_brute_force(icm_handle *h, int on);
+
+/* Keep the per-beam outputs of a sweep (label and running-mean target of every kept beam)
+ * for icm_get_association; off by default (they cost 28 B of HBM traffic per kept beam). */
+int icm_set_debug(icm_handle *h, int on);
+/* With debug on: per pose (T,3) row-major [final energy, NM iterations, function evaluations]
+ * of the last sweep's solve (0 for poses without a solve). */
+int icm_get_solve_diag(icm_handle *h, double *out);
+/* Form in which the pose solves evaluate the observation energy h(x) of
+ * scripts/ICM_ROS.py:171-200 -- the same function in three algebraically identical forms:
+ *   0 (default) moment form: quadratic form in (dp, cos d - 1, sin d) about the pose's
+ *               previous value, 14 sums per pose; one LANE solves a pose
+ *   1           one term per kept beam, literally the reference's sum; one wave per pose
+ *   2           one term per (pose, landmark) entry: k |p + R bbar - y|^2_Q + scatter; one
+ *               wave per pose
+ * Forms 1 and 2 exist to cross-check form 0. */
+int icm_set_energy_form(icm_handle *h, int form);
+
+/* Lanes per pose in the red-black solves: 0 = one lane per pose (throughput form), 1 = one DPP
+ * quad per pose evaluating the four candidate points of a Nelder-Mead iteration at once (latency
+ * form, for colours with fewer poses than the chip has lanes), -1 = automatic (default).
+ * Bit-identical results. */
+int icm_set_solve_lanes(icm_handle *h, int mode);
+
+/* Red-black sweeps in throughput form: 1 (default) = both colours in ONE launch, every
+ * even wave starting as soon as the two odd waves holding its poses' neighbours are done
+ * (k_solve_m_fused); 0 = one launch per colour.  Bit-identical results. */
+int icm_set_colour_fusion(icm_handle *h, int on);
+/* How many times an even wave of the one-launch solve polls for its odd neighbours (~0.2 us per
+ * poll; default 1 << 17) before it DEFERS: it leaves its poses untouched and the fix-up launch
+ * queued right behind (k_solve_m_fix) solves them after the kernel boundary.  Forward
+ * progress therefore never depends on the order workgroups are dispatched in; 0 defers every wave
+ * whose neighbours are not done at its first look (= one launch per colour, through the same
+ * code).  Bit-identical results for every value.  icm_get_fused_deferred: waves deferred so far
+ * over the handle's life (synchronises the stream). */
+int icm_set_fused_spin_limit(icm_handle *h, int polls);
+int icm_get_fused_deferred(icm_handle *h, int64_t *waves);
+
+/* What the one-launch solve evaluates per Nelder-Mead step (fun_xn / fun_x, scripts/ICM_ROS.py:220-278):
+ *   1  the FOLDED form only -- the whole conditional energy as one quadratic in the planar step with 13 per-pose
+ *      coefficients (valid per pose while its heading step stays within 0.25 rad and no angle residual can wrap); a
+ *      pose one of whose evaluations leaves that range is not stored but marked, and the fix-up launches behind
+ *      (k_solve_m_fix, odd then even) solve it -- and the even poses next to a marked odd pose -- with
+ *   0  the complete energy (folded where valid, term by term elsewhere) in the main kernel itself;
+ *  -1  (default) 1 with isotropic weights Q0 == Q1, R0 == R1, else 0 (the folded form never holds then).
+ * Which road a pose takes is decided from its own data and both evaluate identical arithmetic: bit-identical results.
+ * icm_get_fixup_poses: poses solved by the fix-up launches because they were marked, over the handle's life. */
+int icm_set_fold_mode(icm_handle *h, int mode);
+int icm_get_fixup_poses(icm_handle *h, int64_t *poses);
+
+/* Sizes of the staging area of phase A's (pose, landmark) entries for a shard with nnz kept beams and nloc poses (host
+ * arithmetic only, no GPU): out3 = [first place of the sparse area, capacity of the staged-entry arrays, capacity of
+ * each per-entry prefix array].  ICM_ERR_CAPACITY when they exceed 32-bit entry offsets. */
+int icm_staging_layout(int64_t nnz, int64_t nloc, int64_t *out3);
+
+/* Pipeline that turns the per-pose entries into running-mean targets (the time-ordered
+ * per-landmark prefix of Mapa.actualizar, scripts/ICM_SLAM_tools.py:184-196):
+ *   1 / -1 (default) = hierarchical running sums (pose chunks -> superchunks -> per-landmark
+ *       column prefix; no sort); used for the moment-form solves.  A map so dense that a
+ *       64-pose chunk sees more than ~190 distinct landmarks makes the sweep fall back to
+ *   0 = the sort-based pipeline (radix sort of the entries by landmark + one wave per
+ *       landmark), which has no such limit and also serves energy forms 1/2 and icm_set_debug.
+ * The two differ only in the order the per-landmark sums are added up (~1e-15 relative).
+ * icm_get_entry_path: pipeline the last sweep actually ran (0 or 1). */
+int icm_set_entry_path(icm_handle *h, int mode);
+int icm_get_entry_path(const icm_handle *h);
+
+/* Where Mapa.filtrar runs inside a sweep: 1 (default) = on the GPU (the k_fl_* kernel chain on a
+ * side stream: prune, grid, nearest-neighbour pairs, and -- when survivors are closer than dist_thr
+ * -- label propagation, renumbering and count-weighted means; only coincident landmarks, an empty
+ * map or a merge component of more than 7 landmarks go to the host routine), 0 = always the host
+ * routine icm_filtrar.  Same results.
+ * icm_last_filtrar_info: [0] landmarks_actuales after the last sweep's filter, [1] where it ran
+ * (0 GPU, no merges; 1 GPU with merges; 2 host routine), [2] landmarks that had a neighbour closer
+ * than dist_thr (-1 on the host path). */
+int icm_set_gpu_filtrar(icm_handle *h, int on);
+int icm_last_filtrar_info(const icm_handle *h, int64_t *out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICMSLAM_TUNING_H */

@@ -20,5 +20,7 @@ def make(cfg, wl, rank, world, t_begin, t_end):
     from oracle_shard_engine import OracleShardEngine
     ocfg = o.OracleConfig.from_config(cfg)
     scans_BT = np.zeros((wl.B, wl.T))
-    scans_BT[:, t_begin:t_end] = wl.scans.T      # this rank generated only its own shard
+    scans_BT[:, t_begin:t_end] = wl.scans.T      # this rank generated only its own shard ...
+    if t_begin >= 1 and wl.ghost_scan is not None:
+        scans_BT[:, t_begin - 1] = wl.ghost_scan  # ... and the scan of its ghost pose
     return OracleShardEngine(ocfg, scans_BT, wl.u, wl.odometry, t_begin, t_end)

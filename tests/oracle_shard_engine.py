@@ -14,10 +14,15 @@ class OracleShardEngine:
         self.T = odo.shape[1]
         self.a, self.b = t_begin, t_end
         self.kept = {t: o.filtrar_z(scans_BT[:, t], ocfg) for t in range(t_begin, t_end)}
+        # the ghost pose: the last pose of the rank below, solved here as well (icmslam_hip/sharded.py)
+        self.ghost = t_begin - 1 if t_begin >= 2 else None
+        if self.ghost is not None:
+            assert t_begin % 2 == 0, "shards start at even poses"
+            self.kept[self.ghost] = o.filtrar_z(scans_BT[:, self.ghost], ocfg)
         self.L = ocfg.L
 
     def stats_stride(self):
-        return 3 * self.L + 8
+        return 3 * self.L + 16
 
     def bind_tensors(self, stats, poses, rank, world):
         self.stats = stats.numpy().reshape(world, -1)
@@ -56,14 +61,40 @@ class OracleShardEngine:
         row = self.stats[self.rank]
         row[:3 * L] = S.reshape(-1)
         row[3 * L] = n_new
+        row[3 * L + 1] = 0.0
+        # boundary poses as the previous sweep left them: first, last, last but one
+        row[3 * L + 2:3 * L + 5] = self.x[self.a]
+        row[3 * L + 5:3 * L + 8] = self.x[self.b - 1]
+        row[3 * L + 8:3 * L + 11] = self.x[max(self.b - 2, 0)]
         self.n_new = n_new
 
     def sweep_targets(self):
         L, lact0 = self.L, self.lact
         allS = self.stats[:, :3 * L].reshape(self.world, 3, L)
+        # the neighbours' boundary poses (previous-sweep values) out of their headers
+        if self.ghost is not None:
+            below = self.stats[self.rank - 1]
+            self.x[self.a - 1] = below[3 * L + 5:3 * L + 8]
+            self.x[self.a - 2] = below[3 * L + 8:3 * L + 11]
+        if self.b < self.T and self.rank + 1 < self.world:
+            self.x[self.b] = self.stats[self.rank + 1][3 * L + 2:3 * L + 5]
         run = allS[:self.rank, :, :].sum(axis=0)
         run[:, lact0:] = 0.0
         self.targets = {}
+        g = self.ghost
+        if g is not None and self.kept[g].ndim == 2 and self.kept[g].shape[0] > 0:
+            # ghost pose: associated with its owner's previous-sweep value; running means through it inclusive = the
+            # totals of all lower ranks; the landmark it created itself is the last new one of the rank below
+            w = o.project_beams(self.x[g], self.kept[g][:, 2:4])
+            c = o.associate(self.map, min(lact0, self.map.shape[1]), w, self.cfg.dist_thr)
+            tg = np.zeros((c.size, 2))
+            old = c >= 0
+            tg[old] = (run[0:2, c[old]] / run[2, c[old]]).T
+            if np.any(~old):
+                col = lact0 + int(self.stats[self.rank - 1, 3 * L]) - 1
+                sb = allS[self.rank - 1]
+                tg[~old] = sb[0:2, col] / sb[2, col]
+            self.targets[g] = tg
         for t in range(self.a, self.b):
             if t not in self.entries:
                 continue
@@ -87,9 +118,10 @@ class OracleShardEngine:
         self.y_raw, self.cnt_raw, self.lact_raw = y, cnt, col
 
     def sweep_solve(self, schedule, colour):
-        xv = self.x[:self.T].T  # (3,T) view: writes go to the shared buffer
-        first = max(self.a, 1)
-        for t in range(first, self.b):
+        xv = self.x[:self.T].T  # (3,T) view: writes go to this rank's pose array
+        first = max(self.a, 1) if self.ghost is None else self.ghost
+        order = [t for t in range(first, self.b) if t & 1] + [t for t in range(first, self.b) if not t & 1]
+        for t in order:
             if colour >= 0 and (t & 1) != colour:
                 continue
             k = self.kept[t]

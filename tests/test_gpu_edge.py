@@ -162,18 +162,19 @@ def test_s2_full_size_properties():
     eng.close()
     print("S2 mean landmark change per sweep:", ["%.2e" % v for v in cambio], "landmarks", K)
     assert cambio[-1] < 0.5 * cambio[0]
-    # sharded (2 virtual ranks, shared buffers) == unsharded, 2 sweeps
+    # sharded (2 virtual ranks, shared statistics buffer) == unsharded, 2 sweeps
     world = 2
     _, parts = partition(wl.T, world)
-    engines, buffers = [], None
+    engines, runners, stats = [], [], None
     for r, (a, b) in enumerate(parts):
         e = SweepEngine(cfg)
-        e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
-        run = ShardedSweep(e, r, world, wl.T, comm=NoComm(), buffers=buffers)
-        buffers = (run.stats, run.poses)
+        e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.scans[a - 1] if a else None)
+        run = ShardedSweep(e, r, world, wl.T, comm=NoComm(), stats=stats)
+        stats = run.stats
         run.set_state(wl.map_init, wl.x_init, wl.x0)
         engines.append(e)
-    run_virtual_ranks(engines, 2)
+        runners.append(run)
+    run_virtual_ranks(runners, 2)
     torch.cuda.synchronize()
     xs, ms, cs, Ks = engines[0].get_state()
     for e in engines:
@@ -340,9 +341,6 @@ def test_sweep_queued_whole_recovers_from_a_table_overflow():
     class Loopback:   # world size 1: the rank's own statistics are the gathered ones
         def gather_stats(self, sw):
             sw.stats[:sw.stride].copy_(sw.stats_send)
-
-        def halo(self, sw):
-            raise AssertionError("no halo at world size 1")
 
         def all_gather(self, buf, rank, count):
             pass
@@ -728,25 +726,24 @@ def test_non_finite_inputs_do_not_hang():
         eng.close()
 
 
-def test_pipelined_sweep_is_bit_identical_and_recovers_from_overflow():
-    """The two-segment pipelined sweep (phase A/B of one time segment beside the solves of the other,
-    two HIP streams) against the one-stream sweep: S1 over 6 sweeps with state reads, snapshot /
-    restore and host-array sweeps in between -- every state bit-equal."""
+def test_fold_only_solve_with_fixup_is_bit_identical():
+    """The one-launch solve in its fold-only form (13 coefficients per pose, no scratch; poses outside the folded
+    form's range left to the fix-up launches) against the complete energy in the main kernel: S1 over 6 sweeps with
+    state reads, snapshot / restore and host-array sweeps in between -- every state bit-equal."""
     from ICM_SLAM_tools import ConfigICM
     from icmslam_hip import SweepEngine
     from icmslam_hip.synthetic import WORKLOADS, make_workload
     wl = make_workload(*WORKLOADS["S1"])
     cfg = ConfigICM(D=wl.config)
 
-    def run(pipe):
+    def run(mode):
         eng = SweepEngine(cfg)
         eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
-        eng.set_pipeline(pipe)
+        eng.set_fold_mode(mode)
         eng.set_state(wl.map_init, wl.x_init, wl.x0)
-        out, used = [], []
+        out = []
         for it in range(6):
             eng.sweep_device("redblack")
-            used.append(eng.pipeline_used())
             if it == 1:
                 eng.snapshot_state()
             if it in (0, 2, 5):
@@ -757,59 +754,89 @@ def test_pipelined_sweep_is_bit_identical_and_recovers_from_overflow():
         x = out[-1][0].copy()                    # a host-array sweep from there (icm_sweep: set_state + sweep + get_state)
         mo, co, K = eng.sweep(out[-1][1][:, :out[-1][3]], x, wl.x0, out[-1][3], "redblack")
         out.append((x, mo, co, K))
-        nd = eng.fused_deferred()
+        nd, nf = eng.fused_deferred(), eng.fixup_poses()
         eng.close()
-        return out, used, nd
+        return out, nd, nf
 
-    ref, used0, _ = run(False)
-    got, used1, nd = run(True)
-    assert not any(used0) and all(used1)
-    print("pipelined S1: even waves deferred %d" % nd)
-    for a, b in zip(ref, got):
-        for u, v in zip(a, b):
-            assert np.array_equal(u, v)
+    ref, _, nf0 = run(0)
+    got, nd, nf1 = run(1)
+    auto, _, nfa = run(-1)
+    print("fold-only S1: even waves deferred %d, poses solved by the fix-up launches %d (automatic mode: %d)" % (nd, nf1, nfa))
+    assert nf0 == 0 and nfa == nf1      # isotropic weights: automatic = fold-only
+    for a, b, c in zip(ref, got, auto):
+        for u, v, w in zip(a, b, c):
+            assert np.array_equal(u, v) and np.array_equal(u, w)
     # restore + one sweep reproduces sweep 3 of the straight run
     assert np.array_equal(got[3][0], got[1][0]) and np.array_equal(got[3][1], got[1][1])
 
 
-def test_pipelined_sweep_on_the_dataset_and_dense_map_fallback():
-    """data_IJAC2018 (1833 poses, 16-pose chunks) pipelined == unsegmented over three sweeps; a map so
-    dense that a scan overflows the per-pose table makes a pipelined sweep roll its first segment
-    back and finish on the unsegmented path, with the same result."""
+def test_fixup_launches_take_poses_outside_the_folded_range():
+    """Poses whose heading is off by 0.4 rad start their solve outside the folded form's range (|d theta| <= 0.25):
+    the fold-only kernel must leave exactly those -- and the even poses next to a marked odd one -- to the fix-up
+    launches, and the sweep must equal the one with the complete energy in the main kernel, bit for bit, and the C
+    oracle to 1e-9.  Same with anisotropic weights forced through the fold-only kernel (the folded form never holds:
+    every solved pose goes through the fix-up launches)."""
     from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    from oracle import c_oracle as co
+    wl = make_workload(1900, 100, 180)
+    for what, Q in (("kicked headings", [1.0, 1.0]), ("anisotropic Q", [1.0, 1.5])):
+        conf = dict(wl.config)
+        conf["Q"] = Q
+        cfg = ConfigICM(D=conf)
+        x0 = wl.x_init.copy()
+        if what == "kicked headings":
+            x0[2, 45:wl.T - 2:50] += 0.4          # odd poses 45, 95, ...
+            x0[2, 70:wl.T - 2:100] -= 0.4         # even poses 70, 170, ...
+        outs = {}
+        for mode in (0, 1):
+            eng = SweepEngine(cfg)
+            eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+            eng.set_fold_mode(mode)
+            eng.set_state(wl.map_init, x0, wl.x0)
+            for _ in range(2):
+                eng.sweep_device("redblack")
+            outs[mode] = (eng.get_state(), eng.fixup_poses())
+            eng.close()
+        (ref, n0), (got, n1) = outs[0], outs[1]
+        print("%s: poses solved by the fix-up launches %d (of %d pose solves)" % (what, n1, 2 * (wl.T - 1)))
+        assert n0 == 0
+        if what == "kicked headings":
+            assert 30 <= n1 < 400                  # the kicked poses and their even neighbours, not the sequence
+        else:
+            assert n1 >= 2 * (wl.T - 1) - 400      # everything but the no-beam poses of the turn
+        for u, v in zip(ref, got):
+            assert np.array_equal(u, v)
+        kept = co.prefilter(cfg, wl.scans.T)
+        xc, mv, la = x0.copy(), wl.map_init, wl.K
+        for _ in range(2):
+            mv, cnt, la, _ = co.sweep(cfg, kept, wl.u, wl.odometry, wl.x0, mv, xc, la, "redblack")
+        x, m, c, K = got
+        assert K == la and np.array_equal(c, cnt) and np.abs(m[:, :K] - mv).max() <= 1e-9
+        d = np.abs(x - xc).max(axis=0)
+        print("%s vs C oracle: max|dx| %.3e, poses above 1e-9: %d" % (what, d.max(), int((d > 1e-9).sum())))
+        assert d.max() <= 1e-9
+
+
+def test_fold_only_solve_on_the_dataset_sequential_and_redblack():
+    """data_IJAC2018: the reference-order sweep (one chain, complete energy) is untouched by the fold-only form; the
+    red-black sweeps agree between the two forms of the one-launch solve over three sweeps."""
     from icmslam_hip import SweepEngine
     from util import Cfg, dataset, gold
     zz, odo, u = dataset()
     init = gold("init_pass.npz")
     res = []
-    for pipe in (False, True):
+    for mode in (0, 1):
         eng = SweepEngine(Cfg())
         eng.upload(zz, odo, u)
-        eng.set_pipeline(pipe)
+        eng.set_fold_mode(mode)
         eng.set_state(init["map_init"], init["x_init"], odo[:, 0], int(init["landmarks_actuales"]))
         for _ in range(3):
             eng.sweep_device("redblack")
-        res.append((eng.get_state(), eng.pipeline_used()))
+        res.append((eng.get_state(), eng.fixup_poses()))
         eng.close()
-    assert res[0][1] is False and res[1][1] is True
-    for a, b in zip(res[0][0], res[1][0]):
-        assert np.array_equal(a, b)
-    lm, scans, x_true, u2, cfgd = _dense_ring_case()
-    cfg = ConfigICM(D=cfgd)
-    rep = 400                                     # 2400 poses: long enough to be cut into two segments
-    scans_l, odo_l, u_l = np.tile(scans, (1, rep)), np.tile(x_true, (1, rep)), np.tile(u2, (1, rep))
-    res = []
-    for pipe in (False, True):
-        e = SweepEngine(cfg)
-        e.upload(scans_l, odo_l, u_l)
-        e.set_pipeline(pipe)
-        e.set_state(lm, odo_l.copy(), odo_l[:, 0])
-        e.sweep_device("redblack")
-        first = e.pipeline_used()
-        e.sweep_device("redblack")
-        res.append((e.get_state(), first, e.pipeline_used()))
-        e.close()
-    assert res[1][1] is False and res[1][2] is False     # the overflow sent it to the unsegmented path, for good
+    print("data_IJAC2018: poses solved by the fix-up launches over 3 sweeps: %d" % res[1][1])
     for a, b in zip(res[0][0], res[1][0]):
         assert np.array_equal(a, b)
 

@@ -149,15 +149,16 @@ def test_full_s2_on_eight_virtual_ranks_equals_unsharded():
     wl, cfg = _setup("S2")
     world, sweeps = 8, 2
     _, parts = partition(wl.T, world)
-    engines, buffers = [], None
+    engines, runners, stats = [], [], None
     for r, (a, b) in enumerate(parts):
         e = SweepEngine(cfg)
-        e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
-        run = ShardedSweep(e, r, world, wl.T, comm=NoComm(), buffers=buffers)
-        buffers = (run.stats, run.poses)
+        e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.scans[a - 1] if a else None)
+        run = ShardedSweep(e, r, world, wl.T, comm=NoComm(), stats=stats)
+        stats = run.stats
         run.set_state(wl.map_init, wl.x_init, wl.x0)
         engines.append(e)
-    run_virtual_ranks(engines, sweeps)
+        runners.append(run)
+    run_virtual_ranks(runners, sweeps)
     torch.cuda.synchronize()
     states = [e.get_state() for e in engines]
     for e in engines:
@@ -177,3 +178,50 @@ def test_full_s2_on_eight_virtual_ranks_equals_unsharded():
         assert d.max() <= TOL
     for s in states[1:]:
         assert np.array_equal(s[0], states[0][0]) and np.array_equal(s[1], states[0][1])   # replicas agree bit for bit
+    # ... and against the C oracle's full-size fixture (tests/golden/make_s2_fullsize.py): every pose, the map, the counters
+    fx = np.load(os.path.join(GOLD, "s2_fullsize.npz"))
+    xs, ms, cs, Ks = states[0]
+    d = np.abs(xs - fx["x2"]).max(axis=0)
+    print("S2 x8 vs C oracle after sweep 2: K %d/%d  max|dmap| %.2e  max|dx| %.3e  poses above 1e-9: %d"
+          % (Ks, int(fx["K2"]), np.abs(ms[:, :Ks] - fx["map2"]).max(), d.max(), int((d > TOL).sum())))
+    assert Ks == int(fx["K2"]) and np.abs(ms[:, :Ks] - fx["map2"]).max() <= TOL
+    assert np.array_equal(cs[:fx["counts2"].size], fx["counts2"]) and not cs[fx["counts2"].size:].any()
+    assert d.max() <= TOL
+
+
+def test_full_s2_every_pose_against_the_c_oracle_fixture():
+    """BASELINE configs[3], the workload bench.py quotes, at FULL size: HIP state after red-black sweeps 1 and 2 against
+    the C oracle's (tests/golden/s2_fullsize.npz): kept beams and labels of every beam exact (per-pose digests),
+    counters exact, raw map / map and EVERY one of the 100 000 poses <= 1e-9.  This is the size at which the
+    1 563-chunk / 64-superchunk prefix hierarchy, the packed staging plan and the one-launch solve at 782 waves per
+    colour actually run.  (Semantics: scripts/ICM_SLAM_tools.py:167-197, scripts/ICM_ROS.py:141-158.)"""
+    from icmslam_hip import SweepEngine
+    from util import label_digest
+    fx = np.load(os.path.join(GOLD, "s2_fullsize.npz"))
+    wl, cfg = _setup("S2")
+    eng = SweepEngine(cfg)
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    off, bk, d, bx, by = eng.kept_beams()
+    assert int(off[-1]) == int(fx["nnz"]) and np.array_equal(label_digest(off, bk), fx["kept_digest"]), "filtrar_z keeps the same beams"
+    eng.set_state(wl.map_init, wl.x_init, wl.x0)
+    for it in (1, 2):
+        eng.set_debug(True)
+        eng.set_entry_path("hier")          # the product pipeline, with the association dump on
+        eng.sweep_device("redblack")
+        assert eng.entry_path() == "hier"
+        lab = eng.association()[0]
+        yr, cr, lr = eng.raw_map()
+        x, mo, cnt, K = eng.get_state()
+        bad = np.flatnonzero(label_digest(off, lab) != fx["labels%d" % it])
+        assert bad.size == 0, "sweep %d: labels differ on %d poses, first %s" % (it, bad.size, bad[:8])
+        assert lr == int(fx["raw_lact%d" % it]) and np.array_equal(cr[:lr], fx["raw_counts%d" % it])
+        dr = np.abs(yr[:, :lr] - fx["raw_map%d" % it]).max()
+        dm = np.abs(mo[:, :K] - fx["map%d" % it]).max() if K == int(fx["K%d" % it]) else np.inf
+        dx = np.abs(x - fx["x%d" % it]).max(axis=0)
+        print("S2 full size, sweep %d: K %d/%d  labels of %d beams exact  max|draw| %.2e  max|dmap| %.2e  max|dx| %.2e  poses above 1e-9: %d of %d"
+              % (it, K, int(fx["K%d" % it]), lab.size, dr, dm, dx.max(), int((dx > TOL).sum()), wl.T))
+        c2 = fx["counts%d" % it]
+        assert K == int(fx["K%d" % it]) and np.array_equal(cnt[:c2.size], c2) and not cnt[c2.size:].any()
+        assert dr <= TOL and dm <= TOL
+        assert dx.max() <= TOL
+    eng.close()

@@ -1,6 +1,7 @@
-"""The sharded sweep on ONE GPU: several in-process ranks bound to the same exchange buffers
-(the collectives become shared memory), against the unsharded sweep; plus the RCCL
-all-gather path itself with a 1-rank process group."""
+"""The sharded sweep on ONE GPU: several in-process ranks bound to the same statistics buffer
+(the collective becomes shared memory), against the unsharded sweep; the RCCL all-gather path itself
+with a 1-rank process group; three OS processes with the messages carried over gloo -- through the
+torch.distributed driver and through the C library's own driver (icm_comm_init_transport)."""
 import numpy as np
 import pytest
 
@@ -35,16 +36,17 @@ def test_virtual_ranks_match_unsharded(world):
     sweeps = 3
     x1, m1, c1, K1 = _single(wl, cfg, sweeps)
     blk, parts = partition(wl.T, world)
-    engines, runners, buffers = [], [], None
+    assert blk % 2 == 0 and all(a % 2 == 0 for a, _ in parts), "shards are cut at even poses"
+    engines, runners, stats = [], [], None
     for r, (a, b) in enumerate(parts):
         e = SweepEngine(cfg)
-        e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
-        run = ShardedSweep(e, r, world, wl.T, comm=NoComm(), buffers=buffers)
-        buffers = (run.stats, run.poses)
+        e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.scans[a - 1] if a else None)
+        run = ShardedSweep(e, r, world, wl.T, comm=NoComm(), stats=stats)
+        stats = run.stats
         run.set_state(wl.map_init, wl.x_init, wl.x0)
         engines.append(e)
         runners.append(run)
-    run_virtual_ranks(engines, sweeps)
+    run_virtual_ranks(runners, sweeps)
     torch.cuda.synchronize()
     assert all(e.entry_path() == "hier" for e in engines), "the sharded sweep runs the hierarchical pipeline"
     for e in engines:
@@ -120,10 +122,12 @@ def test_library_collectives_refuse_a_wrong_partition():
     e.close()
 
 
-def _native_worker(rank, world, port, out_path):
-    """One rank of a multi-process sharded sweep; every rank uses cuda:0 (one-GPU box), the
-    collectives go through gloo -- the path under test is the library's send-side buffers
-    (icm_bind_exchange_send), halo pack in icm_sweep_solve and icm_halo_unpack."""
+def _native_worker(rank, world, port, out_path, driver):
+    """One rank of a multi-process sharded sweep; every rank uses cuda:0 (one-GPU box), the messages travel over
+    gloo through host memory.  driver "torch": ShardedSweep, the library writes its message into the send buffer
+    (icm_bind_exchange_send) and the test's TorchComm gathers it; driver "library": icm_sweep_sharded -- ONE C call
+    per sweep -- with the same gloo hop plugged in as the library's transport (icm_comm_init_transport)."""
+    import ctypes
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -133,7 +137,7 @@ def _native_worker(rank, world, port, out_path):
     import torch
     import torch.distributed as dist
     from icmslam_hip import SweepEngine
-    from icmslam_hip.sharded import ShardedSweep, TorchComm, partition
+    from icmslam_hip.sharded import LibrarySweep, ShardedSweep, TorchComm, partition
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
 
     class HostHopComm(TorchComm):
@@ -148,26 +152,42 @@ def _native_worker(rank, world, port, out_path):
             assert sw.native
             self._ag(sw.stats, sw.stats_send)
 
-        def halo(self, sw):
-            assert sw.native
-            self._ag(sw.halo_recv, sw.halo_send)
-            sw.eng.halo_unpack()
-
         def all_gather(self, buf, r, count):
             mine = buf[r * count:(r + 1) * count].clone()
             self._ag(buf, mine)
+
+    from util import hip_runtime
+    hip = None   # (resolved at the first call: the runtime is loaded with the library)
+    calls = []
+
+    def gloo_transport(send_ptr, recv_ptr, count, stream_ptr):
+        """icm_allgather_fn: wait for the handle's stream, device -> host, gloo all-gather, host -> device."""
+        hip = hip_runtime()
+        assert hip.hipStreamSynchronize(ctypes.c_void_p(stream_ptr)) == 0
+        mine = torch.empty(count, dtype=torch.float64)
+        allr = torch.empty(count * world, dtype=torch.float64)
+        assert hip.hipMemcpy(ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(send_ptr), ctypes.c_size_t(8 * count), 2) == 0   # D2H
+        dist.all_gather_into_tensor(allr, mine)
+        assert hip.hipMemcpy(ctypes.c_void_p(recv_ptr), ctypes.c_void_p(allr.data_ptr()), ctypes.c_size_t(8 * count * world), 1) == 0   # H2D
+        calls.append(count)
 
     wl, cfg = _workload()
     _, parts = partition(wl.T, world)
     a, b = parts[rank]
     e = SweepEngine(cfg)
-    e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
-    run = ShardedSweep(e, rank, world, wl.T, comm=HostHopComm())
-    assert run.native
+    e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.scans[a - 1] if a else None)
+    if driver == "library":
+        run = LibrarySweep(e, rank, world, wl.T, transport=gloo_transport)
+    else:
+        run = ShardedSweep(e, rank, world, wl.T, comm=HostHopComm())
+        assert run.native
     run.set_state(wl.map_init, wl.x_init, wl.x0)
-    for _ in range(3):
+    sweeps = 3
+    for _ in range(sweeps):
         run.sweep("redblack")
     torch.cuda.synchronize()
+    if driver == "library":
+        assert calls == [e.stats_stride()] * sweeps, "exactly one collective per sweep: %r" % (calls,)
     x, m, c, K = run.get_state()
     np.savez(out_path % rank, x=x, m=m[:, :K], c=c, K=K, path=e.entry_path())
     e.close()
@@ -175,21 +195,90 @@ def _native_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_three_processes_library_side_halo(tmp_path):
-    """Three OS processes (ranks) on the one GPU, real exchanges between them: the library's
-    send buffers + halo pack/unpack give the unsharded result; the interior rank has a
-    neighbour on both sides."""
+@pytest.mark.parametrize("driver", ["torch", "library"])
+def test_three_processes_one_collective_per_sweep(tmp_path, driver):
+    """Three OS processes (ranks) on the one GPU, real exchanges between them (gloo): one all-gather per sweep, the
+    shard's ghost pose instead of a halo exchange -- the unsharded result; the interior rank has a neighbour on both
+    sides.  "library": the C library's sharded driver (icm_sweep_sharded) at world size 3, its collective carried by
+    the transport hook."""
     import torch.multiprocessing as mp
     world = 3
     wl, cfg = _workload()
     x1, m1, c1, K1 = _single(wl, cfg, 3)
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_native_worker, args=(world, 29561, out), nprocs=world, join=True)
-    for r in range(world):
-        g = np.load(out % r)
+    mp.spawn(_native_worker, args=(world, 29561 if driver == "torch" else 29571, out, driver), nprocs=world, join=True)
+    res = [np.load(out % r) for r in range(world)]
+    for r, g in enumerate(res):
         assert str(g["path"]) == "hier"
         assert int(g["K"]) == K1 and np.array_equal(g["c"], c1)
         assert np.abs(g["m"] - m1[:, :K1]).max() <= 1e-9
         d = np.abs(g["x"] - x1).max(axis=0)
-        print("rank %d: max|dx| %.3e, poses above 1e-9: %d" % (r, d.max(), int((d > 1e-9).sum())))
+        print("%s rank %d: max|dx| %.3e, poses above 1e-9: %d" % (driver, r, d.max(), int((d > 1e-9).sum())))
         assert d.max() <= 1e-9
+    for g in res[1:]:
+        assert np.array_equal(g["x"], res[0]["x"]) and np.array_equal(g["m"], res[0]["m"])   # replicas agree bit for bit
+
+
+def _failing_worker(rank, world, port, out_path):
+    """Careful-form failure on ONE rank (its labels exceed L): every rank must come back with the error instead of
+    waiting in the collective."""
+    import ctypes
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "icm-slam_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import LibrarySweep, partition
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from util import hip_runtime
+    hip = None   # (resolved at the first call: the runtime is loaded with the library)
+
+    def gloo_transport(send_ptr, recv_ptr, count, stream_ptr):
+        hip = hip_runtime()
+        assert hip.hipStreamSynchronize(ctypes.c_void_p(stream_ptr)) == 0
+        mine = torch.empty(count, dtype=torch.float64)
+        allr = torch.empty(count * world, dtype=torch.float64)
+        assert hip.hipMemcpy(ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(send_ptr), ctypes.c_size_t(8 * count), 2) == 0
+        dist.all_gather_into_tensor(allr, mine)
+        assert hip.hipMemcpy(ctypes.c_void_p(recv_ptr), ctypes.c_void_p(allr.data_ptr()), ctypes.c_size_t(8 * count * world), 1) == 0
+
+    wl, _ = _workload()
+    conf = dict(wl.config)
+    conf["L"] = wl.K + 2          # room for two new landmarks only
+    cfg = ConfigICM(D=conf)
+    _, parts = partition(wl.T, world)
+    a, b = parts[rank]
+    e = SweepEngine(cfg)
+    e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.scans[a - 1] if a else None)
+    run = LibrarySweep(e, rank, world, wl.T, transport=gloo_transport)
+    x = wl.x_init.copy()
+    # poses of rank 1's block pushed 3 m sideways: every one of its scans leaves the gate and creates a landmark
+    a1, b1 = parts[1]
+    x[1, a1:b1] += 3.0
+    run.set_state(wl.map_init, x, wl.x0)
+    outcome = "ok"
+    try:
+        run.sweep("redblack")
+    except IndexError as ex:
+        outcome = "IndexError: " + str(ex)
+    open(out_path % rank, "w").write(outcome)
+    e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_local_failure_is_collective(tmp_path):
+    """One rank's labels exceed L in phase A (the reference's IndexError, scripts/ICM_SLAM_tools.py:191): it still takes
+    part in the sweep's collective with the error code in its header, and every rank raises -- nobody hangs."""
+    import torch.multiprocessing as mp
+    world = 3
+    out = str(tmp_path / "rank%d.txt")
+    mp.spawn(_failing_worker, args=(world, 29581, out), nprocs=world, join=True)
+    res = [open(out % r).read() for r in range(world)]
+    print(res)
+    assert all(r.startswith("IndexError") for r in res), res

@@ -13,9 +13,10 @@ from util import Cfg, ROOT, dataset, gold
 def test_library_exports_every_declared_symbol():
     from icmslam_hip import _lib
     lib = _lib.load()
-    header = open(os.path.join(ROOT, "include", "icmslam.h")).read()
+    header = "".join(open(os.path.join(ROOT, "include", f)).read() for f in ("icmslam.h", "icmslam_tuning.h"))
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)        # declarations only, not the prose about them
     declared = set(re.findall(r"\b(icm_[a-z_0-9]+)\s*\(", header))
-    declared -= {"icm_stats_stride()"}
+    declared -= {"icm_allgather_fn"}
     assert declared, "no declarations parsed"
     for name in sorted(declared):
         assert hasattr(lib, name), "libicmslam_hip.so lacks %s" % name
@@ -30,6 +31,44 @@ def test_library_collectives_entry_points_without_a_gpu():
     lib = _lib.load()
     assert lib.icm_sweep_sharded(None) != 0 and lib.icm_gather_poses(None) != 0
     assert lib.icm_comm_init(None, None, 0, 1) != 0 and lib.icm_comm_destroy(None) != 0
+
+
+def test_staging_layout_is_consistent_for_every_shape_of_shard():
+    """The one helper that sizes the staging area of phase A's entries, the sparse area behind it and the per-entry
+    prefix arrays (staging_layout, icm_host.hpp; the round-2 out-of-bounds store came from this arithmetic being spread
+    over four functions): for shards with far fewer kept beams than poses, none at all, one-chunk sequences and the S2
+    shape, every place a kernel can address lies inside the arrays."""
+    from icmslam_hip import _lib
+    lib = _lib.load()
+    SLACK, WAVE = 4, 64
+    for nnz, nloc in ((0, 1), (0, 5000), (1, 1), (3, 100000), (37, 2), (64, 16), (1000, 16), (23_000_000, 100_000), (460_000_000, 2_000_000)):
+        out = np.zeros(3, dtype=np.int64)
+        assert lib.icm_staging_layout(nnz, nloc, out.ctypes.data_as(_lib._lp)) == 0
+        sparse0, entries, stride = (int(v) for v in out)
+        # packed area: pose t owns [plan[t] + SLACK t, plan[t+1] + SLACK (t+1)), plan <= nnz: its end for the last pose
+        assert nnz + SLACK * nloc <= sparse0
+        # sparse area: a pose that does not fit stages at sparse0 + (its first kept beam), at most one entry per beam,
+        # and the wave-wide compaction store may run one wave past its last entry
+        assert sparse0 + max(nnz, 1) + WAVE <= entries
+        # the per-entry prefixes live at the same places; k_chunk_l1's branch-free stores reach one more wave
+        assert entries + WAVE <= stride
+        assert stride < 2 ** 31
+    out = np.zeros(3, dtype=np.int64)
+    assert lib.icm_staging_layout(1_200_000_000, 1_000_000, out.ctypes.data_as(_lib._lp)) == _lib.ICM_ERR_CAPACITY   # beyond 32-bit offsets
+    assert lib.icm_staging_layout(-1, 10, out.ctypes.data_as(_lib._lp)) == _lib.ICM_ERR_CAPACITY
+
+
+def test_shard_partition_cuts_at_even_poses():
+    from icmslam_hip import _lib
+    from icmslam_hip.sharded import partition, shard_block
+    lib = _lib.load()
+    for T in (2, 3, 249, 600, 1833, 1900, 100_000, 800_000):
+        for world in (1, 2, 3, 7, 8):
+            blk, parts = partition(T, world)
+            assert blk == shard_block(T, world) == lib.icm_shard_block(T, world) and blk % 2 == 0
+            assert parts[0][0] == 0 and parts[-1][1] == T and all(a % 2 == 0 for a, b in parts if b > a)   # (trailing ranks may be empty)
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            assert all(b - a == blk for a, b in parts if b < T)
 
 
 def test_create_without_gpu_fails_loudly():

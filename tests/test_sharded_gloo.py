@@ -42,8 +42,9 @@ def _worker(rank, world, port, out_path):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_ranks_gloo_match_unsharded_oracle(tmp_path, world):
-    """world 2: one shard boundary; world 3: an interior rank with a halo on both sides (the
-    pose blocks are NOT exchanged per sweep, only the boundary poses are)."""
+    """world 2: one shard boundary; world 3: an interior rank with a neighbour on both sides (the
+    pose blocks are NOT exchanged per sweep: one all-gather of statistics + boundary poses, ghost pose
+    solved redundantly)."""
     from oracle import icm_oracle as o
     out = str(tmp_path / "rank%d.npz")
     mp.spawn(_worker, args=(world, 29533 + world, out), nprocs=world, join=True)

@@ -3,7 +3,7 @@ sys.path.insert(0, 'icm-slam_amd'); sys.path.insert(0, '.')
 import numpy as np, torch
 from ICM_SLAM_tools import ConfigICM
 from icmslam_hip import SweepEngine
-from icmslam_hip.sharded import NoComm, ShardedSweep, partition
+from icmslam_hip.sharded import NoComm, ShardedSweep, partition   # (NoComm: the careful form; neighbours' slots stay zero -- rank 0 and ranks whose ghost pose finds its landmarks' sums are meaningful)
 from icmslam_hip.synthetic import WORKLOADS, make_workload
 T1,K,B = WORKLOADS["S2"]
 for world, rank in ((1,0),(2,1),(8,0),(8,5)):
@@ -11,7 +11,7 @@ for world, rank in ((1,0),(2,1),(8,0),(8,5)):
     blk, parts = partition(T, world)
     a,b = parts[rank]
     wl = make_workload(T,K,B,t_begin=a,t_end=b); cfg = ConfigICM(D=wl.config)
-    eng = SweepEngine(cfg, 0); eng.upload(wl.scans, wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True)
+    eng = SweepEngine(cfg, 0); eng.upload(wl.scans, wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.ghost_scan if rank else None)
     run = ShardedSweep(eng, rank, world, T, comm=NoComm())
     run.set_state(wl.map_init, wl.x_init, wl.x0)
     for _ in range(3): run.sweep("redblack")
