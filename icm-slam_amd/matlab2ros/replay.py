@@ -19,7 +19,10 @@ import math
 import numpy as np
 
 SAMPLE_PERIOD = 0.1          # [s] createbag.py publishes at 10 Hz
-_COV = [0.001 if i in (0, 7, 14) else (100.0 if i in (21, 28, 35) else 0.0) for i in range(36)]
+# The 36-element covariance the reference's publisher sends with every pose and twist (createbag.py:86-88,99-101): its
+# non-zero entries sit at flat indices 0, 6, 12 (0.001) and 18, 24, 30 (100.0) -- every sixth element, NOT the diagonal
+# 0, 7, 14, ... of a row-major 6x6 matrix.  Reproduced as sent (pinned by tests/golden/createbag_messages.json).
+_COV = [0.001 if i in (0, 6, 12) else (100.0 if i in (18, 24, 30) else 0.0) for i in range(36)]
 
 
 def stamp_of(seq, period=SAMPLE_PERIOD):

@@ -166,8 +166,13 @@ def test_synthetic_workload_is_deterministic_and_shardable():
     lo = make_workload(300, 49, 180, t_begin=0, t_end=150)
     hi = make_workload(300, 49, 180, t_begin=150, t_end=300)
     assert lo.scans.shape == (150, 180) and hi.scans.shape == (150, 180)
-    # same geometry in both shards (noise differs per shard by design)
+    # same geometry AND the same range noise whoever generates a pose's scan (counter-based noise stream): an N-rank
+    # job sweeps exactly the N = 1 job's inputs; the scan in front of a shard (its ghost pose) comes with it
     assert np.array_equal(lo.map_init, hi.map_init) and np.array_equal(lo.x_init, a.x_init)
+    assert np.array_equal(lo.scans, a.scans[:150]) and np.array_equal(hi.scans, a.scans[150:])
+    assert lo.ghost_scan is None and np.array_equal(hi.ghost_scan, a.scans[149])
+    odd = make_workload(300, 49, 180, t_begin=77, t_end=201)
+    assert np.array_equal(odd.scans, a.scans[77:201]) and np.array_equal(odd.ghost_scan, a.scans[76])
     hits = (a.scans < 10.0).sum(axis=1)
     assert hits.mean() > 10 and a.scans.min() > 0
 
@@ -215,3 +220,38 @@ def test_message_replay_round_trip_through_the_topic_parsers():
     assert np.array_equal(od[:2], odo_ref[:2, :T]) and np.array_equal(u, u_ref[:, :T])
     dyaw = np.abs(np.angle(np.exp(1j * (od[2] - odo_ref[2, :T]))))
     assert dyaw.max() <= 1e-14          # yaw through the quaternion and back
+
+
+def test_replayed_messages_equal_the_reference_publishers():
+    """Row f4 of the scope table: the LaserScan / Odometry messages matlab2ros/replay.py builds are, field by field,
+    the ones the reference's publisher emits (createbag.py:37-121: mat2laser_scann, mat2odometry, Header.new_message;
+    fixture made by tests/golden/make_golden_messages.py from the imported reference), and the arrays the topic
+    parsers make of the reference's messages are bitwise the ones they make of ours."""
+    import json
+    from matlab2ros import replay
+    from sensors_definitions import Lidar, Odometria
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "createbag_messages.json")))["samples"]
+    d = gold("data_IJAC2018.npz")
+    msgs = list(replay.messages(d["observations"], d["odometry"], d["velocities"]))
+    assert sorted(int(k) for k in fx) == [0, 1, 100, 1832]
+    cfg = Cfg()
+    for k, ref in fx.items():
+        scan, odom = msgs[int(k)]
+        assert scan == ref["laser_scan"], "LaserScan of sample %s differs" % k
+        assert odom == ref["odometry"], "Odometry of sample %s differs" % k
+        assert set(scan) == set(ref["laser_scan"]) and set(odom["header"]) == set(ref["odometry"]["header"])
+        parsed = []
+        for pair in ((scan, odom), (ref["laser_scan"], ref["odometry"])):
+            li, od = Lidar(config=cfg), Odometria(config=cfg)
+            li.callback(pair[0])
+            od.callback(pair[1])
+            parsed.append((li.msgs[0], od.msgs[0]))
+        (la, oa), (lb, ob) = parsed
+        assert la["seq"] == lb["seq"] == int(k) and la["stamp"] == lb["stamp"] and np.array_equal(la["data"], lb["data"])
+        assert oa["stamp"] == ob["stamp"] and np.array_equal(oa["data"]["odo"], ob["data"]["odo"]) and np.array_equal(oa["data"]["u"], ob["data"]["u"])
+        # and the parsed sample is the dataset's (ranges prepared as scripts/sensors_definitions.py:22; the Lidar parser
+        # keeps 180 of the 181 beams like the reference's, :23-29)
+        zz = np.minimum(d["observations"][:, int(k)] + cfg.radio, cfg.rango_laser_max)
+        assert np.array_equal(la["data"][:, 0], zz[:180])
+        assert np.array_equal(oa["data"]["odo"][:2, 0], d["odometry"][:2, int(k)]) and np.array_equal(oa["data"]["u"][:, 0], d["velocities"][:, int(k)])
+        assert abs(oa["data"]["odo"][2, 0] - np.arctan2(np.sin(d["odometry"][2, int(k)]), np.cos(d["odometry"][2, int(k)]))) < 1e-12
