@@ -1,7 +1,7 @@
 # rocprofv3 passes behind profiles/r02_*: run on the GPU box from the repo root,
 #   gpurun -- 'bash tools/profile.sh TAG'
 # kernel-trace/stats and the PMC passes are separate runs (the pool refuses them combined).
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --workload S2 --steps 6 --warmup 2 --cpu-poses 0 --no-roofline --no-extras"
 O=gpurun_out/prof_$TAG
