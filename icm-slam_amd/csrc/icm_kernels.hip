@@ -656,20 +656,25 @@ __device__ __forceinline__ void seg_step_rows(bool take, double& ax, double& ay)
 #ifndef ICM_ASSOC_WPE
 #define ICM_ASSOC_WPE 8
 #endif
+
 template <int HS>
 struct PoseTable {
     int key[HS];
     int cnt[HS];
-    int owner[HS];
     double sx[HS];
     double sy[HS];
+    int owner[HS];
 };
 
 // PPW consecutive poses per wave (1 or more; > 1 only for the plain configuration, with the rotation table): while a
 // pose is grouped, the next pose's header (beam range, pose, rotation -- scalar loads) and its first 64 beams are
 // already in flight, so only the wave's first pose pays the dependent chain beam offsets -> beams -> grid record.
-template <bool PRELABEL, bool DEBUG, int HS, int PPW = 1>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_ASSOC_WPE : 4, HS == 128 ? 8 : 5)))
+// WPB = waves per workgroup.  The waves of a workgroup share nothing here, but a workgroup gives its wave slots back
+// only when its LAST wave ends, and scans differ in length (0 .. 720 kept beams): with four poses per workgroup a sixth
+// of the chip's wave-slot time stood empty behind the longest pose of each group (SQ_WAVE_CYCLES: 6.6 of 8 slots
+// filled on average).  One-wave workgroups recycle every slot the moment its pose is done.
+template <bool PRELABEL, bool DEBUG, int HS, int PPW = 1, int WPB = kWavesPerBlock>
+__global__ __launch_bounds__(WPB * kWave) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_ASSOC_WPE : 4, HS == 128 ? 8 : 5)))
 void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int t_begin, int nloc, const int* __restrict__ boff,
                                                         const double* __restrict__ bx, const double* __restrict__ by,
@@ -682,11 +687,20 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int* __restrict__ st_off = nullptr, const int* __restrict__ plan = nullptr,
                                                         int pose0 = 0, int sparse0 = 0) {
     static_assert(PPW == 1 || (!PRELABEL && !DEBUG), "several poses per wave: plain configuration only");
+    // PPW == 0: PERSISTENT waves -- the grid holds as many waves as the chip has wave slots and wave w takes the poses w,
+    // w + W, w + 2 W, ...  A wave's life is a chain of dependent round trips (beam offsets -> beams -> grid record -> LDS
+    // grouping), and eight waves per SIMD do not cover it (the vector pipe idles a fifth of the time although it is the
+    // busiest unit); a wave that stays can have the NEXT pose's header and first 64 beams -- and the beam offsets of the
+    // pose after that -- in flight while it groups the current one, so only its first pose pays the start-up chain.
+    // (PPW > 1, consecutive poses per short-lived wave, hid the same latency but paid for it in wave quantisation:
+    // 50 000 waves of two poses on 8 192 slots are seven rounds where 6.1 would do.)
+    constexpr bool PERSIST = PPW == 0;
     constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
     constexpr int kHashShift = HS == 128 ? 25 : 24;
-    __shared__ PoseTable<HS> tables[kWavesPerBlock];
+    __shared__ PoseTable<HS> tables[WPB];
     const int lane = lane_id();
-    const int w0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + wave_in_block()) * PPW);
+    const int w0 = __builtin_amdgcn_readfirstlane((blockIdx.x * WPB + wave_in_block()) * (PERSIST ? 1 : PPW));
+    const int stride = PERSIST ? (int)(gridDim.x * WPB) : 1;
     if (w0 >= nloc) return;
     PoseTable<HS>& T = tables[wave_in_block()];
     const GridParams gp = *g.par;
@@ -710,16 +724,39 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         fbx = beam_at(bx + hj0, i0);
         fby = beam_at(by + hj0, i0);
     }
+    int nj0 = 0, nj1 = 0;   // persistent: beam range of the pose after next (scalar loads, two poses ahead)
+    if (PERSIST && w0 + stride < nloc) {
+        nj0 = __builtin_amdgcn_readfirstlane(boff[w0 + stride]);
+        nj1 = __builtin_amdgcn_readfirstlane(boff[w0 + stride + 1]);
+    }
 #pragma unroll 1
-    for (int pp = 0; pp < PPW; ++pp) {
-    const int tl = w0 + pp;
+    for (int pp = 0; PERSIST || pp < PPW; ++pp) {
+    const int tl = w0 + pp * stride;
     if (tl >= nloc) break;
     // (wave-uniform values through scalar registers: the pose's beam range becomes a scalar base pointer plus a
     // 32-bit lane offset)
     const int j0 = hj0, j1 = hj1;
     const double px = hpx, py = hpy, ct = hct, st = hst;
     double nbx = fbx, nby = fby;
-    if (PPW > 1 && pp + 1 < PPW && tl + 1 < nloc) {   // the next pose's header and first beams, requested now
+    if (PERSIST) {
+        const int tn = tl + stride;
+        if (tn < nloc) {   // the next pose's header and first beams, requested now; the beam range of the one after
+            hj0 = nj0;
+            hj1 = nj1;
+            const int t2 = tn + stride;
+            if (t2 < nloc) {
+                nj0 = __builtin_amdgcn_readfirstlane(boff[t2]);
+                nj1 = __builtin_amdgcn_readfirstlane(boff[t2 + 1]);
+            }
+            pose_of(x, x0, t_begin + tn, hpx, hpy, hth);
+            hct = rot[2 * (size_t)tn];
+            hst = rot[2 * (size_t)tn + 1];
+            const unsigned i1 = min((unsigned)lane, (unsigned)max(hj1 - hj0, 1) - 1u);   // (a pose without beams reads one in-range beam nobody uses)
+            const unsigned b1 = (unsigned)min(hj0, max(nnz_total - 1, 0));
+            fbx = beam_at(bx + b1, i1);
+            fby = beam_at(by + b1, i1);
+        }
+    } else if (PPW > 1 && pp + 1 < PPW && tl + 1 < nloc) {   // the next pose's header and first beams, requested now
         hj0 = j1;
         hj1 = __builtin_amdgcn_readfirstlane(boff[tl + 2]);
         pose_of(x, x0, t_begin + tl + 1, hpx, hpy, hth);
@@ -784,7 +821,12 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         const unsigned long long hm = __ballot(head) & ((2ull << lane) - 1ull);
         const int dist = lane - (63 - (int)__builtin_clzll(hm | 1ull));
         const int c = dist + 1;
+        // Segmented inclusive scan of (bx, by) over the runs, over the distance to the run head: at step d a lane at least
+        // d beams into its run adds the partial of lane - d; the partials move through DPP row shifts / row broadcasts.
+        // (Round 3 measured the same scan with the partials travelling through LDS -- one 16-byte write and read per lane
+        // and step, 18 % fewer vector instructions per wave: 0.195 against 0.188 ms, SLOWER)
         double ax = bxx, ay = byy;
+        // (DPP row shifts inside each 16-lane row, then row_bcast:15 / :31 across rows; the run's beam count is dist + 1)
         seg_step<0x111, 0xF>(dist >= 1, ax, ay);
         seg_step<0x112, 0xF>(dist >= 2, ax, ay);
         seg_step<0x114, 0xF>(dist >= 4, ax, ay);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "icm_restore_state": (C.c_int, [_H]),
     "icm_set_colour_fusion": (C.c_int, [_H, C.c_int]),
     "icm_set_fold_mode": (C.c_int, [_H, C.c_int]),
+    "icm_set_assoc_persistence": (C.c_int, [_H, C.c_int]),
     "icm_get_fixup_poses": (C.c_int, [_H, _lp]),
     "icm_staging_layout": (C.c_int, [C.c_int64, C.c_int64, _lp]),
     "icm_set_fused_spin_limit": (C.c_int, [_H, C.c_int]),

@@ -472,6 +472,10 @@ class SweepEngine:
         the fix-up launches, 0 the complete energy in the main kernel (icm_set_fold_mode)."""
         self._chk(self.lib.icm_set_fold_mode(self.h, int(mode)))
 
+    def set_assoc_persistence(self, workgroups_per_cu):
+        """Phase A on persistent waves: workgroups per compute unit (default 8); 0 = one wave per pose."""
+        self._chk(self.lib.icm_set_assoc_persistence(self.h, int(workgroups_per_cu)))
+
     def fixup_poses(self):
         """Poses the fix-up launches solved because a fold-only lane marked them, so far."""
         n = C.c_int64(0)

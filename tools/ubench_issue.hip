@@ -38,6 +38,24 @@ __global__ __launch_bounds__(256) void k(double* out, long long* cyc, int iters)
             REP64(asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(ia));)
         } else if (MODE == 10) {  // 2 indep fma chains with SGPR addend
             REP16(asm volatile("v_fma_f64 %0, %0, %2, %3\n v_fma_f64 %1, %1, %2, %3\n v_fma_f64 %0, %0, %2, %3\n v_fma_f64 %1, %1, %2, %3" : "+v"(a), "+v"(b) : "v"(m), "s"(n));)
+        } else if (MODE == 12) {  // four independent f32 fma chains
+            float fa = (float)a, fb = (float)b, fc = (float)c, fd = (float)d;
+            REP16(asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
+            a = fa; b = fb; c = fc; d = fd;
+        } else if (MODE == 13) {  // four independent packed-f32 fma chains (two f32 per instruction and lane)
+            REP16(asm volatile("v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+        } else if (MODE == 14) {  // four independent dpp movs
+            REP16(asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(ia), "+v"(ib), "+v"(ic), "+v"(id));)
+        } else if (MODE == 15) {  // four independent f64 adds
+            REP16(asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(n));)
+        } else if (MODE == 16) {  // f64 compares into SGPR pairs, independent
+            REP16(asm volatile("v_cmp_lt_f64 vcc, %0, %1\n v_cmp_lt_f64 vcc, %1, %2\n v_cmp_lt_f64 vcc, %2, %3\n v_cmp_lt_f64 vcc, %3, %0" : : "v"(a), "v"(b), "v"(c), "v"(d) : "vcc");)
+        } else if (MODE == 17) {  // the association's mix: 2 f64 : 1 dpp : 4 32-bit, independent
+            REP16(asm volatile("v_fma_f64 %0, %0, %8, %9\n v_add_u32 %4, %4, %5\n v_mul_f64 %1, %1, %8\n v_cndmask_b32 %5, %5, %6, vcc\n v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n v_and_b32 %7, %7, %4\n v_lshlrev_b32 %4, 1, %4\n v_add_f64 %2, %2, %9"
+                               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(ia), "+v"(ib), "+v"(ic), "+v"(id) : "v"(m), "v"(n));)
+        } else if (MODE == 18) {  // scalar ALU beside vector: 1 s_add : 1 v_fma_f64
+            int sa = iters;
+            REP16(asm volatile("v_fma_f64 %0, %0, %4, %5\n s_add_u32 %6, %6, 1\n v_fma_f64 %1, %1, %4, %5\n s_add_u32 %6, %6, 1\n v_fma_f64 %2, %2, %4, %5\n s_add_u32 %6, %6, 1\n v_fma_f64 %3, %3, %4, %5\n s_add_u32 %6, %6, 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "v"(n), "s"(sa) : "scc");)
         } else if (MODE == 11) {  // v_cmp f64 + cndmask dependent
             REP16(asm volatile("v_cmp_lt_f64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_lt_f64 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc" : "+v"(a), "+v"(b), "+v"(ia), "+v"(ib) : : "vcc");)
         }
@@ -66,16 +84,21 @@ void run(const char* name, int blocks, int threads) {
     hipMemcpy(h.data(), cyc, sizeof(long long) * nw, hipMemcpyDeviceToHost);
     double mean = 0; for (auto v : h) mean += v; mean /= nw;
     // readcyclecounter = s_memtime at 100 MHz constant clock? report both
-    printf("%-34s blocks %5d thr %4d: counter ticks/instr %.3f   wall ns/instr(per wave) %.3f\n", name, blocks, threads,
-           mean / (iters * 64.0), ms * 1e6 / (iters * 64.0));
+    // per SIMD: waves on a SIMD = (waves per workgroup / 4) x workgroups per CU (256 CUs)
+    const double wps = (threads / 64) / 4.0 * (blocks <= 256 ? 1.0 : blocks / 256.0);
+    const int per_iter = MODE == 17 || MODE == 18 ? 128 : 64;
+    printf("%-34s blocks %5d thr %4d: counter ticks/instr %.3f   wall ns/instr(per wave) %.3f   SIMD ns/instr %.3f (= %.2f cyc at 2.4 GHz)\n", name, blocks, threads,
+           mean / (iters * (double)per_iter), ms * 1e6 / (iters * (double)per_iter), ms * 1e6 / (iters * (double)per_iter) / (wps < 1 ? 1 : wps),
+           ms * 1e6 / (iters * (double)per_iter) / (wps < 1 ? 1 : wps) * 2.4);
     hipFree(out); hipFree(cyc);
 }
 
 int main() {
     // one wave on the chip; then 1/2/4 waves per SIMD on one CU (256 threads = 4 waves = 1 per SIMD)
-    for (int cfg = 0; cfg < 3; ++cfg) {
-        int blocks = 1, threads = cfg == 0 ? 64 : (cfg == 1 ? 256 : 512);
-        printf("--- %d threads in one workgroup (%s)\n", threads, cfg == 0 ? "lone wave" : cfg == 1 ? "1 wave per SIMD" : "2 waves per SIMD");
+    for (int cfg = 0; cfg < 5; ++cfg) {
+        int blocks = cfg < 3 ? 1 : (cfg == 3 ? 256 * 4 : 256 * 8), threads = cfg == 0 ? 64 : (cfg == 2 ? 512 : 256);
+        printf("--- %d workgroup(s) of %d threads (%s)\n", blocks, threads, cfg == 0 ? "lone wave" : cfg == 1 ? "1 wave per SIMD" : cfg == 2 ? "2 waves per SIMD" :
+               cfg == 3 ? "whole chip, 4 waves per SIMD" : "whole chip, 8 waves per SIMD");
         run<0>("dep fma_f64", blocks, threads);
         run<1>("2 indep fma_f64", blocks, threads);
         run<2>("4 indep fma_f64", blocks, threads);
@@ -88,6 +111,13 @@ int main() {
         run<8>("fma_f64 + 3 cndmask", blocks, threads);
         run<9>("dep mov_dpp", blocks, threads);
         run<11>("cmp_f64+cndmask", blocks, threads);
+        run<12>("4 indep fma_f32", blocks, threads);
+        run<13>("4 indep pk_fma_f32", blocks, threads);
+        run<14>("4 indep mov_dpp", blocks, threads);
+        run<15>("4 indep add_f64", blocks, threads);
+        run<16>("4 indep cmp_f64", blocks, threads);
+        run<17>("mix 3 f64 : 1 dpp : 4 int (x16)", blocks, threads);
+        run<18>("v_fma_f64 + s_add pairs", blocks, threads);
     }
     return 0;
 }
