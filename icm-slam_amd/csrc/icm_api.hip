@@ -135,7 +135,7 @@ struct icm_handle {
     int solve_epoch = 0;
     DevBuf<int> need;         // [nloc + 2]: fold-only solves mark the poses they leave to the fix-up (epoch stamped; slot 0 = ghost pose; [nloc + 1] = need_seen)
     int cu_count = 256;       // compute units of the device (icm_create)
-    int assoc_wave_wgs = 1;   // phase A: one-wave workgroups (1, default) or four poses per 256-thread workgroup (0)
+    int assoc_wave_wgs = 0;   // phase A: four poses per 256-thread workgroup (0, default) or one-wave workgroups (1): measured equal
     int assoc_wg_per_cu = 0;  // phase A on persistent waves: workgroups per CU; 0 (default): one short-lived wave per pose
     int fold_mode = -1;       // -1 automatic (fold-only main kernel + fix-up when the weights are isotropic), 0 never, 1 always
     // ghost pose of a shard (rank > 0): scan, kept beams, staged entries and moments of pose t_begin - 1
@@ -2121,7 +2121,7 @@ int icm_set_fold_mode(icm_handle* h, int mode) {
 int icm_set_assoc_persistence(icm_handle* h, int workgroups_per_cu) {
     if (!h) return ICM_ERR_ARG;
     if (workgroups_per_cu < -1 || workgroups_per_cu > 16) FAIL(h, ICM_ERR_ARG, "icm_set_assoc_persistence: -1 .. 16");
-    h->assoc_wave_wgs = workgroups_per_cu != -1;
+    h->assoc_wave_wgs = workgroups_per_cu == -1;
     h->assoc_wg_per_cu = std::max(workgroups_per_cu, 0);
     return ICM_OK;
 }

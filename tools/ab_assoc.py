@@ -1,7 +1,7 @@
 """A/B of phase A's launch form on S2 (one MI355X): k_assoc_group on persistent waves (workgroups per CU) against one
 short-lived wave per pose; per-kernel HIP-event times and the whole sweep, same box, interleaved.
 
-    python tools/ab_assoc.py [wg_per_cu ...]      # default -1 0 8 (-1: four poses per workgroup, 0: one-wave workgroups, n: persistent)
+    python tools/ab_assoc.py [wg_per_cu ...]      # default -1 0 8 (0: four poses per workgroup, -1: one-wave workgroups, n: persistent)
 """
 import sys, time
 sys.path.insert(0, 'icm-slam_amd'); sys.path.insert(0, '.')

@@ -1,7 +1,7 @@
 """What ONE rank of a strong-scaled S2 job costs per sweep on one MI355X, collectives excluded:
 the rank runs alone through the exchange path a real job takes -- its own message looped back, its neighbours' slots
-filled once with stand-ins (the rank below: this rank's own statistics, so that the ghost pose's running means exist;
-boundary poses from the initial state) -- for world sizes 1 / 2 / 4 / 8, rank 0 (no ghost pose) and rank 1 (ghost pose
+filled once with stand-ins (the rank below: every landmark seen 100 times at its map position, so that the ghost pose's
+running means exist and no landmark is pruned; boundary poses from the initial state) -- for world sizes 1 / 2 / 4 / 8, rank 0 (no ghost pose) and rank 1 (ghost pose
 and a neighbour on both sides).
 
     python tools/shard_cost_strong.py [careful]        # careful: host look at phase A's flags in the middle of every sweep
@@ -31,10 +31,12 @@ class SoloComm:
         self.filled = True
         a, b = sw.own
         x = torch.tensor(np.ascontiguousarray(self.wl.x_init.T), dtype=torch.float64, device=sw.stats.device)
-        if sw.rank > 0:                 # the rank below: statistics that cover the ghost pose's landmarks, its last two poses
-            lo = sw.stats[(sw.rank - 1) * st:sw.rank * st]
-            lo.copy_(sw.stats_send)
-            lo[st - HDR:st - HDR + 2].zero_()
+        if sw.rank > 0:                 # the rank below: every landmark observed 100 times at its map position (so that the
+            lo = sw.stats[(sw.rank - 1) * st:sw.rank * st]   # ghost pose's running means exist and nothing is pruned), its last two poses
+            lo.zero_()
+            L, K = (st - HDR) // 3, self.wl.K
+            m = torch.tensor(self.wl.map_init, dtype=torch.float64, device=sw.stats.device)
+            lo[0:K].copy_(100.0 * m[0]); lo[L:L + K].copy_(100.0 * m[1]); lo[2 * L:2 * L + K].fill_(100.0)
             lo[st - HDR + 5:st - HDR + 8].copy_(x[a - 1])
             lo[st - HDR + 8:st - HDR + 11].copy_(x[a - 2])
         if sw.rank + 1 < sw.world:      # the rank above: its first pose
