@@ -61,6 +61,61 @@ def test_virtual_ranks_match_unsharded(world):
         e.close()
 
 
+@pytest.mark.parametrize("case", ["blind boundaries", "odd length", "five poses, one-pose last shard"])
+def test_virtual_ranks_edge_shards(case):
+    """Shard boundaries where it hurts: the ghost pose, the shard's first pose and its last pose WITHOUT kept beams (the
+    reference's midpoint rule, scripts/ICM_ROS.py:143-147, on both sides of a cut); a sequence of odd length whose last
+    shard is a single pose (solved one-sided from its ghost)."""
+    import torch
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import NoComm, ShardedSweep, partition, run_virtual_ranks
+    from icmslam_hip.synthetic import make_workload
+    wl, cfg = _workload()
+    scans, T = wl.scans.copy(), wl.T
+    world = 3
+    if case == "blind boundaries":
+        _, parts = partition(T, world)
+        for a, b in parts[1:]:
+            scans[a - 2:a + 1] = 10.0            # poses a - 2, a - 1 (the ghost) and a see nothing
+    elif case == "odd length":
+        T = 1269                                 # blocks of 424: the last pose (1268, even) is solved one-sided
+        scans = scans[:T]
+        assert partition(T, world)[1][2] == (848, 1269)
+    else:
+        T = 5                                    # [0, 2) [2, 4) [4, 5): the last rank owns ONE pose, the sequence's last
+        scans = scans[:T]
+        assert partition(T, world)[1] == [(0, 2), (2, 4), (4, 5)]
+    odo, u, x_init = wl.odometry[:, :T], wl.u[:, :T], np.ascontiguousarray(wl.x_init[:, :T])
+    sweeps = 3
+    e1 = SweepEngine(cfg)
+    e1.upload(scans, odo, u, pose_major=True)
+    e1.set_state(wl.map_init, x_init, wl.x0)
+    for _ in range(sweeps):
+        e1.sweep_device("redblack")
+    x1, m1, c1, K1 = e1.get_state()
+    e1.close()
+    _, parts = partition(T, world)
+    engines, runners, stats = [], [], None
+    for r, (a, b) in enumerate(parts):
+        e = SweepEngine(cfg)
+        e.upload(scans[a:b], odo, u, t_begin=a, t_end=b, pose_major=True, ghost_scan=scans[a - 1] if a else None)
+        run = ShardedSweep(e, r, world, T, comm=NoComm(), stats=stats)
+        stats = run.stats
+        run.set_state(wl.map_init, x_init, wl.x0)
+        engines.append(e)
+        runners.append(run)
+    run_virtual_ranks(runners, sweeps)
+    torch.cuda.synchronize()
+    for e in engines:
+        x, m, c, K = e.get_state()
+        d = np.abs(x - x1).max(axis=0)
+        print("%s: max|dx| %.3e, poses above 1e-9: %d" % (case, d.max(), int((d > 1e-9).sum())))
+        assert K == K1 and np.array_equal(c, c1) and np.abs(m[:, :K] - m1[:, :K1]).max() <= 1e-9
+        assert d.max() <= 1e-9
+        e.close()
+
+
 def test_rccl_all_gather_path_one_rank():
     """ShardedSweep with the real torch.distributed 'nccl' (= RCCL) backend, world size 1:
     same result as the plain device-resident sweep."""
