@@ -610,6 +610,12 @@ __global__ __launch_bounds__(kBlock) void k_scan_labels(const double* __restrict
 //   PRELABEL: labels come from `label` (brute-force cross-check) instead of the grid search
 //   DEBUG:    also write label[] and the beam -> entry map bloc[]
 // ---------------------------------------------------------------------------------------
+// ds_add_f64 without a return value (gfx90a and later): an LDS double accumulates in place
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+    typedef __attribute__((address_space(3))) double lds_double;
+    (void)__builtin_amdgcn_ds_atomic_fadd_f64((lds_double*)p, v);
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_mov_i(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
@@ -821,6 +827,14 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         const unsigned long long hm = __ballot(head) & ((2ull << lane) - 1ull);
         const int dist = lane - (63 - (int)__builtin_clzll(hm | 1ull));
         const int c = dist + 1;
+        const int nexthead = dpp_mov_i<0x130, 0xF>(head ? 1 : 0);   // wave_shl:1 (lane 63 reads 0): no LDS round trip
+        bool tail = valid && (lane == cn - 1 || nexthead);
+        // Run tails claim / find the slot of their label in the pose's LDS table.  The compare-and-swap on the label's
+        // home slot goes out NOW, in front of the segmented scan (vector / DPP work only), whose instructions cover its
+        // round trip; it either claims the free slot or reports who holds it.
+        int slot = (int)(((unsigned)lab * 2654435761u) >> kHashShift);
+        int held = kEmpty;
+        if (tail) held = atomicCAS(&T.key[slot], kEmpty, lab);
         // Segmented inclusive scan of (bx, by) over the runs, over the distance to the run head: at step d a lane at least
         // d beams into its run adds the partial of lane - d; the partials move through DPP row shifts / row broadcasts.
         // (Round 3 measured the same scan with the partials travelling through LDS -- one 16-byte write and read per lane
@@ -835,56 +849,32 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         // predicate names the receiving rows itself, so the lanes the DPP move leaves alone need no preset zero
         seg_step_rows<0x142, 0xA>(((lane & 16) != 0) & (dist > (lane & 15)), ax, ay);   // run began in an earlier row
         seg_step_rows<0x143, 0xC>((lane >= 32) & (dist > (lane & 31)), ax, ay);          // run began in rows 0-1
-        const int nexthead = dpp_mov_i<0x130, 0xF>(head ? 1 : 0);   // wave_shl:1 (lane 63 reads 0): no LDS round trip
-        bool tail = valid && (lane == cn - 1 || nexthead);
-        // run tails claim / find the slot of their label
-        int slot = 0;
+        // ... the slot search goes on only where the home slot holds another label (linear probing; a probe IS the
+        // compare-and-swap: one LDS round trip per step instead of a read and then a swap)
         bool inserted = false, found = false;
         if (tail) {
-            slot = (int)(((unsigned)lab * 2654435761u) >> kHashShift);
             // bounded: the table is checked against its 3/4 budget only between chunks, and one
             // chunk can bring up to 64 new labels -- a full table must end the probe, not spin
             for (int probes = 0; probes < kHash; ++probes) {
-                const int k = T.key[slot];
-                if (k == lab) {
+                if (held == kEmpty || held == lab) {
+                    inserted = held == kEmpty;
                     found = true;
                     break;
                 }
-                if (k == kEmpty) {
-                    const int old = atomicCAS(&T.key[slot], kEmpty, lab);
-                    if (old == kEmpty || old == lab) {
-                        inserted = old == kEmpty;
-                        found = true;
-                        break;
-                    }
-                }
                 slot = (slot + 1) & (kHash - 1);
+                held = atomicCAS(&T.key[slot], kEmpty, lab);
             }
-            if (found) T.owner[slot] = lane;
         }
         if (__ballot(tail && !found) != 0ull) overflow = true;   // more distinct landmarks than slots
         tail = tail && found;
         nent += __popcll(__ballot(inserted));
-        __builtin_amdgcn_wave_barrier();
-        const bool lose = tail && T.owner[slot] != lane;
-        if (__ballot(lose) == 0ull) {
-            if (tail) {
-                T.cnt[slot] += c;
-                T.sx[slot] += ax;
-                T.sy[slot] += ay;
-            }
-        } else {  // two runs of one label in this chunk: fold them in lane order
-            unsigned long long m = __ballot(tail);
-            while (m) {
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (lane == l) {
-                    T.cnt[slot] += c;
-                    T.sx[slot] += ax;
-                    T.sy[slot] += ay;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+        // The run's totals are ADDED to the slot by LDS atomics (ds_add_u32 / ds_add_f64, no return value): no
+        // read-modify-write round trip, and two runs of one label inside a batch (a landmark seen left and right of an
+        // occluder) need no arbitration -- the LDS serialises the two additions itself, in one fixed order.
+        if (tail) {
+            atomicAdd(&T.cnt[slot], c);
+            lds_add_f64(&T.sx[slot], ax);
+            lds_add_f64(&T.sy[slot], ay);
         }
         if (DEBUG) {  // every beam learns the slot of its run (from the run's tail)
             const unsigned long long tm = __ballot(tail);
