@@ -56,6 +56,13 @@ __global__ __launch_bounds__(256) void k(double* out, long long* cyc, int iters)
         } else if (MODE == 18) {  // scalar ALU beside vector: 1 s_add : 1 v_fma_f64
             int sa = iters;
             REP16(asm volatile("v_fma_f64 %0, %0, %4, %5\n s_add_u32 %6, %6, 1\n v_fma_f64 %1, %1, %4, %5\n s_add_u32 %6, %6, 1\n v_fma_f64 %2, %2, %4, %5\n s_add_u32 %6, %6, 1\n v_fma_f64 %3, %3, %4, %5\n s_add_u32 %6, %6, 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "v"(n), "s"(sa) : "scc");)
+        } else if (MODE == 19) {  // scalar ALU only: four independent s_add chains
+            int sa = iters, sb2 = iters + 1, sc = iters + 2, sd = iters + 3;
+            REP16(asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1" : "+s"(sa), "+s"(sb2), "+s"(sc), "+s"(sd) : : "scc");)
+            ia += sa + sb2 + sc + sd;
+        } else if (MODE == 20) {  // scalar-heavy mix: 3 scalar : 1 vector (s_and_b64 / s_cmp / s_add : v_fma_f64)
+            int sa = iters;
+            REP16(asm volatile("v_fma_f64 %0, %0, %2, %3\n s_add_u32 %4, %4, 1\n s_and_b64 vcc, vcc, exec\n s_cmp_lg_u32 %4, 0\n v_fma_f64 %1, %1, %2, %3\n s_add_u32 %4, %4, 1\n s_and_b64 vcc, vcc, exec\n s_cmp_lg_u32 %4, 0" : "+v"(a), "+v"(b) : "v"(m), "v"(n), "s"(sa) : "scc", "vcc");)
         } else if (MODE == 11) {  // v_cmp f64 + cndmask dependent
             REP16(asm volatile("v_cmp_lt_f64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_lt_f64 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc" : "+v"(a), "+v"(b), "+v"(ia), "+v"(ib) : : "vcc");)
         }
@@ -86,7 +93,7 @@ void run(const char* name, int blocks, int threads) {
     // readcyclecounter = s_memtime at 100 MHz constant clock? report both
     // per SIMD: waves on a SIMD = (waves per workgroup / 4) x workgroups per CU (256 CUs)
     const double wps = (threads / 64) / 4.0 * (blocks <= 256 ? 1.0 : blocks / 256.0);
-    const int per_iter = MODE == 17 || MODE == 18 ? 128 : 64;
+    const int per_iter = MODE == 17 || MODE == 18 || MODE == 20 ? 128 : 64;
     printf("%-34s blocks %5d thr %4d: counter ticks/instr %.3f   wall ns/instr(per wave) %.3f   SIMD ns/instr %.3f (= %.2f cyc at 2.4 GHz)\n", name, blocks, threads,
            mean / (iters * (double)per_iter), ms * 1e6 / (iters * (double)per_iter), ms * 1e6 / (iters * (double)per_iter) / (wps < 1 ? 1 : wps),
            ms * 1e6 / (iters * (double)per_iter) / (wps < 1 ? 1 : wps) * 2.4);
@@ -118,6 +125,8 @@ int main() {
         run<16>("4 indep cmp_f64", blocks, threads);
         run<17>("mix 3 f64 : 1 dpp : 4 int (x16)", blocks, threads);
         run<18>("v_fma_f64 + s_add pairs", blocks, threads);
+        run<19>("4 indep s_add_u32 (scalar only)", blocks, threads);
+        run<20>("1 v_fma_f64 : 3 scalar", blocks, threads);
     }
     return 0;
 }
