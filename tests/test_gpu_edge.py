@@ -819,6 +819,39 @@ def test_fixup_launches_take_poses_outside_the_folded_range():
         assert d.max() <= 1e-9
 
 
+def test_fixup_launches_with_deferred_waves_and_quad_form():
+    """The fix-up launches carry two kinds of work at once: poses a fold-only lane marked and even waves that deferred.
+    With the poll budget at 0 EVERY even wave whose odd neighbours are not done at its first look defers; with kicked
+    headings some odd poses are marked on top of that -- lane form and quad form, all against the complete-energy kernel
+    with the default poll budget: bit-identical."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    wl = make_workload(1900, 100, 180)
+    cfg = ConfigICM(D=wl.config)
+    x0 = wl.x_init.copy()
+    x0[2, 45:wl.T - 2:50] += 0.4
+    x0[2, 70:wl.T - 2:100] -= 0.4
+    outs = []
+    for fold, lanes, spin in ((0, 0, None), (1, 0, 0), (1, 1, 0), (1, 1, None), (0, 1, 0)):
+        eng = SweepEngine(cfg)
+        eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+        eng.set_fold_mode(fold)
+        eng.set_solve_lanes(lanes)
+        if spin is not None:
+            eng.set_fused_spin_limit(spin)
+        eng.set_state(wl.map_init, x0, wl.x0)
+        for _ in range(3):
+            eng.sweep_device("redblack")
+        outs.append((eng.get_state(), eng.fused_deferred(), eng.fixup_poses()))
+        eng.close()
+    print("deferred waves / fix-up poses per configuration:", [(o[1], o[2]) for o in outs])
+    assert outs[1][1] > 0 and outs[1][2] > 0, "both kinds of fix-up work occurred together"
+    for o in outs[1:]:
+        for a, b in zip(outs[0][0], o[0]):
+            assert np.array_equal(a, b)
+
+
 def test_fold_only_solve_on_the_dataset_sequential_and_redblack():
     """data_IJAC2018: the reference-order sweep (one chain, complete energy) is untouched by the fold-only form; the
     red-black sweeps agree between the two forms of the one-launch solve over three sweeps."""
