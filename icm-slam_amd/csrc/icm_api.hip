@@ -1,9 +1,11 @@
-// C-ABI of the MI355X-native ICM sweep (include/icmslam.h): handle, HBM buffers, sweep
-// orchestration.  Device work goes to one HIP stream, plus a side stream for the fused map
-// filter (the k_fl_* chain), overlapped with the pose
-// solves.  Host round trips per sweep: one 12-byte read-back (entry / new-landmark counts --
-// rocPRIM needs the sort size) and one 16-byte read-back of the filter result; Mapa.filtrar
-// falls back to the host routine only when landmarks have to be merged.
+// C-ABI of the MI355X-native ICM sweep (include/icmslam.h, include/icmslam_tuning.h): handle, HBM buffers, sweep
+// orchestration.  Device work goes to one HIP stream, plus a side stream for the fused map filter (the k_fl_* chain,
+// overlapped with the pose solves) and one for a shard's ghost-pose chain.  A red-black sweep through the default
+// pipeline is queued WHOLE: the host waits once, for the side stream's 16-byte counts-and-flags copy and the filter
+// result, while the solves are still running; the kernels that would replace state look at the sweep's overflow flags
+// themselves.  Only a table overflow (the sweep is then repeated with the host looking in the middle) or a map that
+// needs the exact host routine of Mapa.filtrar adds host round trips.  A sharded sweep has ONE collective, issued here
+// (icm_sweep_sharded: RCCL resolved with dlopen, or the caller's all-gather) or by the caller between the phase calls.
 #include <cstdlib>
 #include <cstring>
 
