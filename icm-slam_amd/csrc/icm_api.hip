@@ -74,6 +74,8 @@ struct icm_handle {
     int64_t T = 0, B = 0, t_begin = 0, nloc = 0;
     bool uploaded = false, prefiltered = false, have_state = false;
     DevBuf<double> ranges, cosb, sinb, odo, u;
+    DevBuf<double> odo_cs;    // (T,2): (cos, sin) of the odometry headings (k_odo_trig, once per sequence)
+    DevBuf<double> pose_cs;   // (T,2): (cos, sin)(theta) of every pose as it stands (valid with rot_valid)
     DevBuf<int> nkept, boff, bk;
     DevBuf<double> bd, bx, by, pose_s2;
     std::vector<int> h_boff;
@@ -382,7 +384,7 @@ int icm_destroy(icm_handle* h) {
     h->e_key.release();
     h->skey.release();
     h->sort_tmp.release();
-    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release(); h->solve_counts.release(); h->need.release();
+    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release(); h->solve_counts.release(); h->need.release(); h->odo_cs.release(); h->pose_cs.release();
     h->gh_ranges.release(); h->gh_bd.release(); h->gh_bx.release(); h->gh_by.release(); h->gh_s2.release(); h->gh_sx.release(); h->gh_sy.release();
     h->gh_rot.release(); h->gh_m.release(); h->gh_nkept.release(); h->gh_boff.release(); h->gh_bk.release(); h->gh_label.release(); h->gh_bloc.release();
     h->gh_st_label.release(); h->gh_misc.release(); h->gh_st_k.release();
@@ -456,6 +458,10 @@ int icm_upload(icm_handle* h, const double* ranges, const double* odo, const dou
     HIPCHK(h, hipMemcpyAsync(h->sinb.p, sinb, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->odo.p, odo, 3 * (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->u.p, u, 2 * (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, h->odo_cs.reserve(2 * (size_t)T));
+    HIPCHK(h, h->pose_cs.reserve(2 * (size_t)T));
+    k_odo_trig<<<nblocks_threads(T), kBlock, 0, h->stream>>>(h->odo.p, (int)T, h->odo_cs.p);
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->uploaded = true;
     h->ghost_uploaded = false;
@@ -776,7 +782,7 @@ __global__ void k_set_header(double* stats, int L, double n_new, double flags, c
 // t_begin - 1 (the ghost pose; its predecessor t_begin - 2 comes with it, and the ghost's rotation pair is formed from
 // its owner's value), above = the pose index t_begin + nloc; -1 = none.
 __global__ void k_halo_from_headers(double* __restrict__ x, const double* __restrict__ stats_all, int stride, int L, int rank,
-                                    int below, int above, double* __restrict__ ghost_rot) {
+                                    int below, int above, double* __restrict__ ghost_rot, double* __restrict__ cs) {
     const int i = threadIdx.x;
     if (i < 3) {
         if (below >= 0) {
@@ -792,6 +798,18 @@ __global__ void k_halo_from_headers(double* __restrict__ x, const double* __rest
             pose_rot(stats_all[(size_t)(rank - 1) * stride + 3 * (size_t)L + 7], ct, st);
             ghost_rot[0] = ct;
             ghost_rot[1] = st;
+        }
+    } else if (i == 7) {
+        // the (cos, sin)(theta) pairs of the two poses copied in below the shard: the ghost solve reads them (the pose above
+        // is only ever a "next" pose, whose heading enters no cos / sin)
+        if (below >= 0 && cs) {
+            const double* hd = stats_all + (size_t)(rank - 1) * stride + 3 * (size_t)L;
+            cs[2 * (size_t)below] = cos(hd[7]);
+            cs[2 * (size_t)below + 1] = sin(hd[7]);
+            if (below >= 1) {
+                cs[2 * (size_t)(below - 1)] = cos(hd[10]);
+                cs[2 * (size_t)(below - 1) + 1] = sin(hd[10]);
+            }
         }
     }
 }
@@ -912,7 +930,7 @@ int icm_sweep_local(icm_handle* h) {
     } while (0)
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
     if (!h->rot_valid) {   // (the poses came from the host, a snapshot or a solve form that does not keep the table)
-        TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p)));
+        TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p, h->pose_cs.p)));
         h->rot_valid = true;
     }
     if (h->brute)
@@ -1096,7 +1114,7 @@ int icm_sweep_targets(icm_handle* h) {
         const int below = ghost ? a - 1 : -1;
         const int above = (b < (int)h->T && h->rank + 1 < h->world) ? b : -1;
         if (below >= 0 || above >= 0)
-            k_halo_from_headers<<<1, 8, 0, h->stream>>>(h->x, h->stats_all, (int)icm_stats_stride(h), L, h->rank, below, above, ghost ? h->gh_rot.p : nullptr);
+            k_halo_from_headers<<<1, 8, 0, h->stream>>>(h->x, h->stats_all, (int)icm_stats_stride(h), L, h->rank, below, above, ghost ? h->gh_rot.p : nullptr, h->pose_cs.p);
     }
     if (h->path_used == 1) {
         const int nrec = h->nchunks * kT1;
@@ -1172,6 +1190,8 @@ static SolveArgs solve_args(icm_handle* h) {
     a.Q0 = h->cfg.Q[0]; a.Q1 = h->cfg.Q[1]; a.cte = h->cfg.cte_odom;
     a.diag = nullptr;
     a.rot = h->rot.p;
+    a.odo_cs = h->odo_cs.p;
+    a.cs = h->pose_cs.p;
     a.need = h->need.p;
     a.need_seen = h->need.p + h->nloc + 1;
     a.epoch = 0;

@@ -466,18 +466,20 @@ __device__ __forceinline__ double pose_energy(const SolveCtx& c, const Items& it
 // Fill the x-independent parts of the context for pose t.
 //   xa = x[:,t-1], xp = x[:,t+1] (ignored if !two_sided), ua = u[:,t-1], ut = u[:,t],
 //   oa/ot/op = odometria[:,t-1], [:,t], [:,t+1]
-__device__ __forceinline__ void make_ctx(SolveCtx& c, int two_sided, const double xa[3],
-                                         const double xp[3], const double ua[2],
-                                         const double ut[2], const double oa[3],
-                                         const double ot[3], const double op[3]) {
+//   ca, sa = cos / sin of xa[2]; coa, soa of oa[2]; cot, sot of ot[2] (two-sided only): the caller has them -- from the
+//   tables whoever wrote the value keeps beside it, or computed on the spot
+__device__ __forceinline__ void make_ctx_t(SolveCtx& c, int two_sided, const double xa[3],
+                                           const double xp[3], const double ua[2],
+                                           const double ut[2], const double oa[3],
+                                           const double ot[3], const double op[3], double ca, double sa,
+                                           double coa, double soa, double cot, double sot) {
     c.two_sided = two_sided;
     c.xax = xa[0]; c.xay = xa[1]; c.xat = xa[2];
-    c.ca = cos(xa[2]); c.sa = sin(xa[2]);
+    c.ca = ca; c.sa = sa;
     // g(a, u_{t-1}) (reference scripts/ICM_ROS.py:202-207)
     c.gax = xa[0] + c.dt * (c.ca * ua[0]);
     c.gay = xa[1] + c.dt * (c.sa * ua[0]);
     c.gat = xa[2] + c.dt * ua[1];
-    const double coa = cos(oa[2]), soa = sin(oa[2]);
     const double d1x = ot[0] - oa[0], d1y = ot[1] - oa[1];
     c.o1x = coa * d1x + soa * d1y;
     c.o1y = -soa * d1x + coa * d1y;
@@ -490,7 +492,6 @@ __device__ __forceinline__ void make_ctx(SolveCtx& c, int two_sided, const doubl
         c.xpx = xp[0]; c.xpy = xp[1]; c.xpt = xp[2];
         c.v = ut[0]; c.w = ut[1];
         c.dtv = c.dt * ut[0]; c.dtw = c.dt * ut[1];
-        const double cot = cos(ot[2]), sot = sin(ot[2]);
         const double d2x = op[0] - ot[0], d2y = op[1] - ot[1];
         c.o2x = cot * d2x + sot * d2y;
         c.o2y = -sot * d2x + cot * d2y;
@@ -499,6 +500,14 @@ __device__ __forceinline__ void make_ctx(SolveCtx& c, int two_sided, const doubl
     } else {
         c.xpx = c.xpy = c.xpt = c.v = c.w = c.o2x = c.o2y = c.o2t = 0.0;
     }
+}
+
+__device__ __forceinline__ void make_ctx(SolveCtx& c, int two_sided, const double xa[3],
+                                         const double xp[3], const double ua[2],
+                                         const double ut[2], const double oa[3],
+                                         const double ot[3], const double op[3]) {
+    const double cot = two_sided ? cos(ot[2]) : 1.0, sot = two_sided ? sin(ot[2]) : 0.0;
+    make_ctx_t(c, two_sided, xa, xp, ua, ut, oa, ot, op, cos(xa[2]), sin(xa[2]), cos(oa[2]), sin(oa[2]), cot, sot);
 }
 
 struct Vtx {

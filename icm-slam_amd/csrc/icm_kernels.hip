@@ -359,8 +359,10 @@ __device__ __forceinline__ void pose_rot(double th, double& ct, double& st) {
 // (cos, sin)(theta - pi/2) of every pose of the shard, once per sweep: phase A and the moment kernel
 // read them instead of every wavefront re-deriving its pose's pair (a generic FP64 sincos is ~150
 // vector instructions, 15 % of a k_assoc_group wave).  rot[2 tl], rot[2 tl + 1].
+// cs (nullable, indexed by the GLOBAL pose): (cos, sin)(theta) of x[:, t] itself -- what the pose solves need of a
+// neighbour's and of the pose's own previous heading (make_ctx, make_fold); kept by whoever writes a pose, like rot.
 __global__ __launch_bounds__(kBlock) void k_pose_rot(const double* __restrict__ x, const double* __restrict__ x0, int t_begin,
-                                                     int nloc, double* __restrict__ rot) {
+                                                     int nloc, double* __restrict__ rot, double* __restrict__ cs = nullptr) {
     const int tl = blockIdx.x * kBlock + threadIdx.x;
     if (tl >= nloc) return;
     double px, py, th, ct, st;
@@ -368,6 +370,21 @@ __global__ __launch_bounds__(kBlock) void k_pose_rot(const double* __restrict__ 
     pose_rot(th, ct, st);
     rot[2 * (size_t)tl] = ct;
     rot[2 * (size_t)tl + 1] = st;
+    if (cs) {
+        const double t0 = x[3 * (size_t)(t_begin + tl) + 2];
+        cs[2 * (size_t)(t_begin + tl)] = cos(t0);
+        cs[2 * (size_t)(t_begin + tl) + 1] = sin(t0);
+    }
+}
+
+// (cos, sin) of the odometry headings, once per sequence (they are the sequence's constants; every pose solve used to
+// form four of them with the generic cos / sin: ~500 vector instructions at the head of every lane's serial chain)
+__global__ __launch_bounds__(kBlock) void k_odo_trig(const double* __restrict__ odo, int T, double* __restrict__ out) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= T) return;
+    const double th = odo[2 * (size_t)T + t];
+    out[2 * (size_t)t] = cos(th);
+    out[2 * (size_t)t + 1] = sin(th);
 }
 
 // Gated nearest landmark of the world point (wx, wy).  The three cell rows around the point
@@ -2104,6 +2121,8 @@ struct SolveArgs {
     double* diag;         // optional (T,3): f, nit, nfev per pose
     double* rot;          // optional (nloc,2): (cos, sin)(theta - pi/2) of the solved pose, the table phase A and the
                           // moment kernel of the NEXT sweep read (k_pose_rot's values: whoever writes a pose writes its pair)
+    const double* odo_cs; // (T,2): (cos, sin) of the odometry headings (k_odo_trig)
+    double* cs;           // (T,2): (cos, sin)(theta) of every pose as it stands (k_pose_rot / store_pose_tables / the headers)
     // fold-only solves (k_solve_m_fused<., true>) and their fix-up (k_solve_m_fix):
     int* need;            // [nloc + 1], slot tl + 1 (slot 0 = the ghost pose): epoch of the launch that left the pose to the fix-up
     int* need_seen;       // one word: the latest epoch in which any pose was marked (the fix-up launches look here first)
@@ -2115,7 +2134,7 @@ struct SolveArgs {
 };
 
 // Result of one pose solve -> x (write-through when other waves of the same launch wait for it) and the rotation table.
-__device__ __forceinline__ void store_pose(const SolveArgs& a, int tg, const double res[3], bool publish) {
+__device__ __forceinline__ void store_pose_xyz(const SolveArgs& a, int tg, const double res[3], bool publish) {
     if (publish) {
         __hip_atomic_store(&a.x[3 * (size_t)tg], res[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.x[3 * (size_t)tg + 1], res[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2125,12 +2144,25 @@ __device__ __forceinline__ void store_pose(const SolveArgs& a, int tg, const dou
         a.x[3 * (size_t)tg + 1] = res[1];
         a.x[3 * (size_t)tg + 2] = res[2];
     }
+}
+// The pairs kept beside a pose: (cos, sin)(theta - pi/2) for phase A / the moment kernel of the next sweep, (cos, sin)(theta)
+// for the next solves.  Two generic sincos, ~260 vector instructions: in the one-launch solve they come AFTER the wave has
+// published its poses (nobody in this launch reads them), off the odd -> even hand-off.
+__device__ __forceinline__ void store_pose_tables(const SolveArgs& a, int tg, double th) {
     if (a.rot && tg >= a.t_begin) {   // (the ghost's pair is recomputed from its owner's value: k_halo_from_headers)
         double ct, st;
-        pose_rot(res[2], ct, st);
+        pose_rot(th, ct, st);
         a.rot[2 * (size_t)(tg - a.t_begin)] = ct;
         a.rot[2 * (size_t)(tg - a.t_begin) + 1] = st;
     }
+    if (a.cs) {
+        a.cs[2 * (size_t)tg] = cos(th);
+        a.cs[2 * (size_t)tg + 1] = sin(th);
+    }
+}
+__device__ __forceinline__ void store_pose(const SolveArgs& a, int tg, const double res[3], bool publish) {
+    store_pose_xyz(a, tg, res, publish);
+    store_pose_tables(a, tg, res[2]);
 }
 
 __device__ __forceinline__ void load3(const double* __restrict__ a, int T, int t, double o[3]) {
@@ -2379,47 +2411,82 @@ __global__ __launch_bounds__(kWave) void k_ghost_moments(const double* __restric
 
 // One LANE (QUAD: one DPP quad, role = lane & 3) solves pose tg with the moment-form energy.
 // `prev` = x[:,tg-1] as it stands now.
+// Everything a pose solve reads that the launch it runs in does not write: loaded BEFORE an even wave of the one-launch
+// solve starts to wait for its odd neighbours, so that what is left behind the wait is the two neighbour poses, one
+// sincos and the folding.
+struct PoseIn {
+    int n;                     // kept beams of the pose (0: the midpoint rule, nothing else is loaded)
+    double ua0, ua1, ut0, ut1; // u[:, t-1], u[:, t]
+    double oa[3], ot[3], op[3];
+    double coa, soa, cot, sot; // (cos, sin) of the odometry headings t-1 and t (k_odo_trig)
+    double pm[17];             // the moment sums
+    double pox, poy, tho, co, so;   // the pose's previous-sweep value and its (cos, sin) (the cs table)
+};
+
+__device__ __forceinline__ void load_pose_in(const SolveArgs& a, int tg, PoseIn& in) {
+    const int tl = tg - a.t_begin;   // (-1: the shard's ghost pose)
+    in.n = tl < 0 ? a.ghost_n : a.boff[tl + 1] - a.boff[tl];
+    if (in.n == 0) return;
+    const bool last = tg + 1 >= a.T;
+    in.ua0 = a.u[tg - 1]; in.ua1 = a.u[(size_t)a.T + tg - 1];
+    load3(a.odo, a.T, tg - 1, in.oa);
+    load3(a.odo, a.T, tg, in.ot);
+    in.coa = a.odo_cs[2 * (size_t)(tg - 1)]; in.soa = a.odo_cs[2 * (size_t)(tg - 1) + 1];
+    in.ut0 = in.ut1 = 0.0; in.op[0] = in.op[1] = in.op[2] = 0.0; in.cot = 1.0; in.sot = 0.0;
+    if (!last) {
+        in.ut0 = a.u[tg]; in.ut1 = a.u[(size_t)a.T + tg];
+        load3(a.odo, a.T, tg + 1, in.op);
+        in.cot = a.odo_cs[2 * (size_t)tg]; in.sot = a.odo_cs[2 * (size_t)tg + 1];
+    }
+    const double* pm = tl < 0 ? a.ghost_m : a.pose_m + tl;
+    const size_t st_ = tl < 0 ? (size_t)1 : (size_t)a.nloc;
+#pragma unroll
+    for (int q = 0; q < 17; ++q) in.pm[q] = pm[q * st_];
+    // expansion point = this pose's previous-sweep value (still in x: nobody else writes it)
+    in.pox = a.x[3 * (size_t)tg]; in.poy = a.x[3 * (size_t)tg + 1]; in.tho = a.x[3 * (size_t)tg + 2];
+    in.co = a.cs[2 * (size_t)tg]; in.so = a.cs[2 * (size_t)tg + 1];
+}
+
 // FOLD: the Nelder-Mead evaluates the folded form only (pose_energy_fold_only) and the function returns false -- res
 // then means nothing -- as soon as one evaluation of this pose left the form's validity range: the caller marks the
 // pose for the fix-up launch, which repeats the solve with FOLD = false (folded where valid, term by term elsewhere).
+// prev = x[:, tg-1] as it stands now; prev_in_table: its (cos, sin) are in the cs table (it was written before this
+// launch began) -- else they are formed here.
 template <bool QUAD, bool FOLD = false>
-__device__ __forceinline__ bool solve_pose_moments(const SolveArgs& a, int tg, const double prev[3], double res[3], int role = 0) {
-    const int tl = tg - a.t_begin;   // (-1: the shard's ghost pose)
-    const int n = tl < 0 ? a.ghost_n : a.boff[tl + 1] - a.boff[tl];
+__device__ __forceinline__ bool solve_pose_in(const SolveArgs& a, int tg, const PoseIn& in, const double prev[3], bool prev_in_table,
+                                              double& r0, double& r1, double& r2, int role = 0) {
     const bool last = tg + 1 >= a.T;
-    if (n == 0) {  // no beams (scripts/ICM_ROS.py:143-147)
+    if (in.n == 0) {  // no beams (scripts/ICM_ROS.py:143-147)
         const double* nx = a.x + 3 * (size_t)(tg + 1);
         const double p0 = tg == 1 ? a.x0[0] : prev[0], p1 = tg == 1 ? a.x0[1] : prev[1], p2 = tg == 1 ? a.x0[2] : prev[2];
-        res[0] = (p0 + nx[0]) / 2.0;
-        res[1] = (p1 + nx[1]) / 2.0;
-        res[2] = (p2 + nx[2]) / 2.0;
+        r0 = (p0 + nx[0]) / 2.0;
+        r1 = (p1 + nx[1]) / 2.0;
+        r2 = (p2 + nx[2]) / 2.0;
         return true;
     }
     SolveCtx c;
     c.dt = a.dt; c.R0 = a.R0; c.R1 = a.R1; c.R2 = a.R2; c.Q0 = a.Q0; c.Q1 = a.Q1; c.cte = a.cte;
-    double xp[3] = {0, 0, 0}, ua[2], ut[2] = {0, 0}, oa[3], ot[3], op[3] = {0, 0, 0};
-    ua[0] = a.u[tg - 1]; ua[1] = a.u[(size_t)a.T + tg - 1];
-    load3(a.odo, a.T, tg - 1, oa);
-    load3(a.odo, a.T, tg, ot);
+    double xp[3] = {0, 0, 0};
     if (!last) {
         xp[0] = a.x[3 * (size_t)(tg + 1)]; xp[1] = a.x[3 * (size_t)(tg + 1) + 1]; xp[2] = a.x[3 * (size_t)(tg + 1) + 2];
-        ut[0] = a.u[tg]; ut[1] = a.u[(size_t)a.T + tg];
-        load3(a.odo, a.T, tg + 1, op);
     }
-    make_ctx(c, !last, prev, xp, ua, ut, oa, ot, op);
+    double ca, sa;
+    if (prev_in_table) {
+        ca = a.cs[2 * (size_t)(tg - 1)];
+        sa = a.cs[2 * (size_t)(tg - 1) + 1];
+    } else {
+        ca = cos(prev[2]);
+        sa = sin(prev[2]);
+    }
+    const double ua[2] = {in.ua0, in.ua1}, ut[2] = {in.ut0, in.ut1};
+    make_ctx_t(c, !last, prev, xp, ua, ut, in.oa, in.ot, in.op, ca, sa, in.coa, in.soa, in.cot, in.sot);
     PoseMoments m;
-    const double* pm = tl < 0 ? a.ghost_m : a.pose_m + tl;
-    const size_t st_ = tl < 0 ? (size_t)1 : (size_t)a.nloc;
-    m.S = pm[0]; m.Swx = pm[st_]; m.Swy = pm[2 * st_]; m.Srx = pm[3 * st_]; m.Sry = pm[4 * st_];
-    m.Swxx = pm[5 * st_]; m.Swyy = pm[6 * st_]; m.Swxy = pm[7 * st_]; m.Swxrx = pm[8 * st_]; m.Swyrx = pm[9 * st_];
-    m.Swxry = pm[10 * st_]; m.Swyry = pm[11 * st_]; m.Srxx = pm[12 * st_]; m.Sryy = pm[13 * st_];
-    m.cxx = pm[14 * st_]; m.cxy = pm[15 * st_]; m.cyy = pm[16 * st_];
+    m.S = in.pm[0]; m.Swx = in.pm[1]; m.Swy = in.pm[2]; m.Srx = in.pm[3]; m.Sry = in.pm[4];
+    m.Swxx = in.pm[5]; m.Swyy = in.pm[6]; m.Swxy = in.pm[7]; m.Swxrx = in.pm[8]; m.Swyrx = in.pm[9];
+    m.Swxry = in.pm[10]; m.Swyry = in.pm[11]; m.Srxx = in.pm[12]; m.Sryy = in.pm[13];
+    m.cxx = in.pm[14]; m.cxy = in.pm[15]; m.cyy = in.pm[16];
     finish_moments(c, m);
-    // expansion point = this pose's previous-sweep value (still in x: nobody else writes it)
-    m.pox = a.x[3 * (size_t)tg]; m.poy = a.x[3 * (size_t)tg + 1];
-    m.tho = a.x[3 * (size_t)tg + 2];
-    m.so = sin(m.tho);  // (no sincos(&member): an address-taken struct member forces scratch)
-    m.co = cos(m.tho);
+    m.pox = in.pox; m.poy = in.poy; m.tho = in.tho; m.co = in.co; m.so = in.so;
     PoseFold f;
     make_fold(c, m, f);
     double sx, sy, st;
@@ -2446,13 +2513,22 @@ __device__ __forceinline__ bool solve_pose_moments(const SolveArgs& a, int tg, c
     } else {
         nelder_mead3([&](double px, double py, double th) { return pose_energy_moments(c, m, f, px, py, th); }, sx, sy, st, out);
     }
-    res[0] = out[0]; res[1] = out[1]; res[2] = out[2];
+    r0 = out[0]; r1 = out[1]; r2 = out[2];
     if (a.diag && role == 0) {
         a.diag[3 * (size_t)tg] = out[3];
         a.diag[3 * (size_t)tg + 1] = out[4];
         a.diag[3 * (size_t)tg + 2] = out[5];
     }
     return true;
+}
+
+// load + solve in one go (the launches in which nothing waits between the two)
+template <bool QUAD, bool FOLD = false>
+__device__ __forceinline__ bool solve_pose_moments(const SolveArgs& a, int tg, const double prev[3], bool prev_in_table, double res[3],
+                                                   int role = 0) {
+    PoseIn in;
+    load_pose_in(a, tg, in);
+    return solve_pose_in<QUAD, FOLD>(a, tg, in, prev, prev_in_table, res[0], res[1], res[2], role);
 }
 
 // A time segment of the sequence solved by one launch: poses [t0, t1).  shift = 0 for the segment
@@ -2485,7 +2561,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, SolveSeg
     if (tg >= g.t1) return;
     double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
     double res[3];
-    solve_pose_moments<false>(a, tg, prev, res);
+    solve_pose_moments<false>(a, tg, prev, true, res);   // (prev was written before this launch began: its pair is in the table)
     store_pose(a, tg, res, false);
 }
 
@@ -2515,36 +2591,6 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, SolveSeg
 // with the complete energy.  An even pose next to a marked odd one cannot be solved here either (its neighbour
 // is not final): it marks itself too.  Marking is decided per pose from the pose's own data, and the fix-up
 // runs the arithmetic the FOLD = false kernel runs, so the sweep's result does not depend on which road a pose took.
-template <bool QUAD, bool FOLD>
-__device__ __forceinline__ void solve_wave_poses(const SolveArgs& a, const SolveSeg& g, bool even, int wv, int lane) {
-    constexpr int PPW = QUAD ? kWave / 4 : kWave;   // poses per wave
-    const int role = QUAD ? (lane & 3) : 0;
-    const int j = wv * PPW + (QUAD ? lane >> 2 : lane);
-    const int tg = seg_pose(g, even, j);
-    if (tg < g.t1) {   // (whole quads together)
-        const int q = tg - a.t_begin + 1;   // slot of need[]
-        bool solved = true;
-        double res[3];
-        if (FOLD && even) {   // a neighbour left to the fix-up is not final
-            const bool dep = (a.need[q - 1] == a.epoch) | (tg + 1 < g.t1 && a.need[q + 1] == a.epoch);
-            solved = !dep;
-        }
-        if (solved) {
-            double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
-            solved = solve_pose_moments<QUAD, FOLD>(a, tg, prev, res, role);
-        }
-        if (role == 0) {
-            // (odd poses are handed to the even waves of this launch: write-through (sc1) stores, no cache-wide release needed)
-            if (solved) {
-                store_pose(a, tg, res, !even);
-            } else {
-                __hip_atomic_store(&a.need[q], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.need_seen, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every writer stores the same value)
-            }
-        }
-    }
-}
-
 #ifdef ICM_WAVE_TS   // measurement builds only (tools/wave_timeline.py): per-wave start / go / end times
 __device__ unsigned long long g_wave_ts[4 * 16384];
 #define WAVE_TS(slot) do { if (lane == 0 && gw < 16384) g_wave_ts[4 * gw + (slot)] = wall_clock64(); } while (0)
@@ -2561,7 +2607,16 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
     const int epoch = a.epoch;
     const bool even = gw >= nw;
     const int wv = even ? gw - nw : gw;
+    constexpr int PPW = QUAD ? kWave / 4 : kWave;   // poses per wave
+    const int role = QUAD ? (lane & 3) : 0;
+    const int tg = seg_pose(g, even, wv * PPW + (QUAD ? lane >> 2 : lane));
+    const bool mine = tg < g.t1;   // (whole quads together)
     WAVE_TS(0);
+    // everything this launch does not write -- moment sums, odometry, controls, the pose's own previous value and the
+    // trigonometry kept beside them -- is requested BEFORE an even wave starts to wait for its odd neighbours
+    PoseIn in;
+    in.n = 0;
+    if (mine) load_pose_in(a, tg, in);
     if (even) {
         int ready = 1;
         if (lane == 0) {
@@ -2585,13 +2640,40 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     WAVE_TS(1);
-    solve_wave_poses<QUAD, FOLD>(a, g, even, wv, lane);
+    bool solved = false;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;   // (three scalars, not an array: an array that lives across the branches goes to scratch)
+    if (mine) {
+        const int q = tg - a.t_begin + 1;   // slot of need[]
+        solved = true;
+        if (FOLD && even) {   // a neighbour left to the fix-up is not final
+            const bool dep = (a.need[q - 1] == epoch) | (tg + 1 < g.t1 && a.need[q + 1] == epoch);
+            solved = !dep;
+        }
+        if (solved) {
+            double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
+            // an odd pose's lower neighbour is an OLD even pose (its pair is in the table); an even pose's was written a
+            // moment ago by an odd wave of this launch, which publishes the pose, not the pair
+            solved = solve_pose_in<QUAD, FOLD>(a, tg, in, prev, !even, r0, r1, r2, role);
+        }
+        if (role == 0) {
+            // (odd poses are handed to the even waves of this launch: write-through (sc1) stores, no cache-wide release needed)
+            if (solved) {
+                const double res[3] = {r0, r1, r2};
+                store_pose_xyz(a, tg, res, !even);
+            } else {
+                __hip_atomic_store(&a.need[q], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.need_seen, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every writer stores the same value)
+            }
+        }
+    }
     WAVE_TS(2);
     if (!even) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every write-through store of this wave has been acknowledged
         if (lane == 0) __hip_atomic_store(&flags[wv], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         WAVE_TS(3);
     }
+    // the rotation pairs kept beside the poses are next sweep's business: behind the hand-off
+    if (mine && solved && role == 0) store_pose_tables(a, tg, r2);
 }
 
 // The fix-up launches behind k_solve_m_fused, one per colour (odd first): the poses a fold-only lane marked in
@@ -2618,7 +2700,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fix(SolveArgs a, SolveSeg g,
         if (mine) {
             double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
             double res[3];
-            solve_pose_moments<QUAD, false>(a, tg, prev, res, role);
+            solve_pose_moments<QUAD, false>(a, tg, prev, true, res, role);
             if (role == 0) store_pose(a, tg, res, false);
         }
     }
@@ -2642,7 +2724,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, SolveSe
     if (tg >= g.t1) return;  // whole quads leave together
     double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
     double res[3];
-    solve_pose_moments<true>(a, tg, prev, res, role);
+    solve_pose_moments<true>(a, tg, prev, true, res, role);
     if (role == 0) store_pose(a, tg, res, false);
 }
 
@@ -2654,7 +2736,7 @@ __global__ __launch_bounds__(kWave) void k_solve_m_sequential(SolveArgs a) {
     double prev[3] = {a.x[0], a.x[1], a.x[2]};
     for (int tg = 1; tg < a.T; ++tg) {
         double res[3];
-        solve_pose_moments<true>(a, tg, prev, res, role);
+        solve_pose_moments<true>(a, tg, prev, false, res, role);   // (prev is the pose this lane has just solved)
         if (role == 0) store_pose(a, tg, res, false);
         prev[0] = res[0]; prev[1] = res[1]; prev[2] = res[2];
     }
