@@ -78,8 +78,9 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True):
         # per entry: k 4, rotated mean 16, target 16; per pose: pose 24, scatter 24, 17 moments out
         # hierarchical pipeline: staged k + sums 18, prefix + record slot 20, record prefix 24 (L2-resident gather)
         "k_pose_moments": (E * (18 + 20 + 24) if hier else E * 36) + nloc * (24 + 24 + 136 + 8),
-        # both colours together, per pose: 17 moments, own + 2 neighbour poses, odometry 72, u 32, pose out 24
-        "k_solve": nloc * (136 + 72 + 72 + 32 + 24 + 8),
+        # both colours together, per pose: 17 moments, own + 2 neighbour poses, odometry 72, u 32, pose out 24, beam offsets 8;
+        # trigonometry tables: odometry pairs 32 + own and lower neighbour's pairs 32 in, rotation pair + (cos, sin) pair 32 out
+        "k_solve": nloc * (136 + 72 + 72 + 32 + 24 + 8 + 96),
         "k_scan": nloc * 16,
         "k_pose_rot": nloc * (24 + 16),
     }
