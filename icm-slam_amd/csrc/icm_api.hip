@@ -241,7 +241,7 @@ static inline int nblocks_threads(int64_t n) { return (int)((n + kBlock - 1) / k
 
 extern "C" {
 
-const char* icm_version(void) { return "icmslam-hip 0.2 (gfx950)"; }
+const char* icm_version(void) { return "icmslam-hip 0.3 (gfx950)"; }
 
 int icm_flop_per_eval(void) { return ICM_FLOP_PER_EVAL; }
 int icm_valu_per_eval(void) { return ICM_VALU_PER_EVAL; }
