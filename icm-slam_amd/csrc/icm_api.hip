@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: a launch with its own stop event
 #include <rccl/rccl.h>   // types and prototypes only: the library is dlopen()ed (icm_comm_init), never linked
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -138,6 +139,10 @@ struct icm_handle {
     int solve_flag_waves = 0;
     int solve_epoch = 0;
     DevBuf<int> need;         // [nloc + 2]: fold-only solves mark the poses they leave to the fix-up (epoch stamped; slot 0 = ghost pose; [nloc + 1] = need_seen)
+    int* fl = nullptr;        // this sweep's block of 16 flag / counter words: the sweeps alternate between the two halves of `flags`,
+    int fl_parity = 0;        //   and k_lm_l3 clears the other half for the next sweep (no memset launch at a sweep's head)
+    bool fl_next_clean = false;
+    bool counts_on_side = false;   // this sweep's 16-byte counts-and-flags copy goes over the side stream (icm_sweep_targets)
     int cu_count = 256;       // compute units of the device (icm_create)
     int assoc_wave_wgs = 0;   // phase A: four poses per 256-thread workgroup (0, default) or one-wave workgroups (1): measured equal
     int assoc_wg_per_cu = 0;  // phase A on persistent waves: workgroups per CU; 0 (default): one short-lived wave per pose
@@ -555,7 +560,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->ent_off.reserve((size_t)nloc + 1)); HIPCHK(h, h->new_rank.reserve((size_t)nloc + 1));
     HIPCHK(h, hipMemsetAsync(h->ent_off.p, 0, ((size_t)nloc + 1) * sizeof(int), h->stream));   // (no reservation plan yet: k_assoc_group)
     const size_t L = (size_t)h->cfg.L;
-    HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(16));   // [0..7] the sweep's flags and host words, [8..9] totals of a sweep without scan kernels
+    HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(32)); h->fl = h->flags.p; h->fl_parity = 0; h->fl_next_clean = false;   // [0..7] the sweep's flags and host words, [8..9] totals of a sweep without scan kernels
     HIPCHK(h, h->stats_own.reserve(3 * L + 8)); HIPCHK(h, h->off_sx.reserve(L)); HIPCHK(h, h->off_sy.reserve(L));
     HIPCHK(h, h->off_n.reserve(L));
     {
@@ -820,7 +825,7 @@ static FiltrarArgs filtrar_args(icm_handle* h) {
     fa.y_raw = h->y_raw.p; fa.cnt_raw = h->cnt_raw.p; fa.stats_all = h->world > 1 ? h->stats_all : nullptr;
     // landmarks created this sweep (single rank): the total of the new-landmark scan, or, in a sweep without the scan
     // kernels, the count k_chunk_l1 added up
-    fa.n_new_dev = h->scan_ran ? h->new_rank.p + h->nloc : h->flags.p + 9;
+    fa.n_new_dev = h->scan_ran ? h->new_rank.p + h->nloc : h->fl + 9;
     fa.sweep_flags = nullptr;
     fa.L = L; fa.lact0 = h->lact0; fa.world = h->world; fa.stride = (int)icm_stats_stride(h);
     fa.cota = h->cfg.cota; fa.thr = h->cfg.dist_thr; fa.max_cells = h->max_cells;
@@ -848,7 +853,7 @@ static void launch_grid_chain(icm_handle* h, hipStream_t fs, const FiltrarArgs& 
 static int launch_filtrar(icm_handle* h, hipStream_t fs, bool guarded = false) {
     const int L = (int)h->cfg.L;
     FiltrarArgs fa = filtrar_args(h);
-    if (guarded) fa.sweep_flags = h->flags.p;   // queued without a host look at the sweep's flags: the kernels look themselves
+    if (guarded) fa.sweep_flags = h->fl;   // queued without a host look at the sweep's flags: the kernels look themselves
     const int nb = std::min(kFlMaxBlocks, (L + kFB - 1) / kFB);
     const int chunk = ((L + nb - 1) / nb + kFB - 1) / kFB * kFB;
     TIMED(h, KID_FILTRAR, (k_fl_count<<<nb, kFB, 0, fs>>>(fa, chunk)));
@@ -909,7 +914,10 @@ int icm_sweep_local(icm_handle* h) {
     h->lact0 = (int)h->lact;
     const int km = (int)std::min(h->K, h->lact);
     const int nbw = nblocks_waves(nloc);
-    HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 16 * sizeof(int), h->stream));
+    h->fl_parity ^= 1;
+    h->fl = h->flags.p + 16 * h->fl_parity;
+    if (!h->fl_next_clean) HIPCHK(h, hipMemsetAsync(h->fl, 0, 16 * sizeof(int), h->stream));   // (else the last sweep's k_lm_l3 cleared it)
+    h->fl_next_clean = false;
     GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p};
     const bool dbg = h->debug || h->per_beam;
     h->assoc_kept = dbg;
@@ -917,7 +925,7 @@ int icm_sweep_local(icm_handle* h) {
     // once (assoc_wg_per_cu per CU: 8 with the 128-slot table, half of that with the 256-slot one), each wave striding
     // over the poses with the next pose's header and first beams in flight.  assoc_wg_per_cu == 0: one pose per wave.
 #define ASSOC_ARGS h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
-        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->flags.p, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->stl.sparse0
+        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->fl, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->stl.sparse0
 #define ASSOC_GROUP(PRE, DBG, HS)                                                                                  \
     do {                                                                                                           \
         const int wgs__ = h->assoc_wg_per_cu * h->cu_count / (HS == 128 ? 1 : 2);                                  \
@@ -965,30 +973,34 @@ int icm_sweep_local(icm_handle* h) {
     TIMED(h, KID_CHUNK_L1, (k_chunk_l1<CH><<<nblocks_waves(h->nchunks), kBlock, 0, h->stream>>>(                          \
         h->x, h->x0.p, (int)h->t_begin, nloc, h->nchunks, h->st_off.p, h->nent.p, h->ent_off.p, h->new_rank.p, h->lact0, \
         h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pre_x.p, h->pre_y.p, h->pre_n.p,                                   \
-        h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->flags.p, 0,                           \
-        run_scan ? nullptr : h->flags.p + 8, h->isnew.p, h->chunk_pub.p, h->scan_epoch, 1 << 16)))
+        h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec, h->fl, 0,                           \
+        run_scan ? nullptr : h->fl + 8, h->isnew.p, h->chunk_pub.p, h->scan_epoch, 1 << 16)))
             if (h->chunk_poses == 64) CHUNK_L1(64); else if (h->chunk_poses == 32) CHUNK_L1(32); else CHUNK_L1(16);
 #undef CHUNK_L1
             if (!h->ms_clean) HIPCHK(h, hipMemsetAsync(ms, 0, 3 * msn * sizeof(double), h->stream));
             h->ms_clean = false;
             TIMED(h, KID_CHUNK_L2, (k_chunk_l2<<<h->nsuper, kT1, 0, h->stream>>>(
                 h->nchunks, h->chunk_group, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
-                h->rec_off.p, h->rec_off.p + nrec, h->rec_off.p + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->flags.p)));
+                h->rec_off.p, h->rec_off.p + nrec, h->rec_off.p + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->fl)));
             double* stats_mine = h->world > 1 ? stats_slot(h) : nullptr;
-            TIMED(h, KID_LM_L3, (k_lm_l3<<<(L + kWave - 1) / kWave, kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, run_scan ? h->new_rank.p + nloc : h->flags.p + 9, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p, run_scan ? h->ent_off.p + nloc : h->flags.p + 8, h->flags.p)));
+            TIMED(h, KID_LM_L3, (k_lm_l3<<<(L + kWave - 1) / kWave, kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, run_scan ? h->new_rank.p + nloc : h->fl + 9, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p, run_scan ? h->ent_off.p + nloc : h->fl + 8, h->fl, 0, -1, nullptr, nullptr, 1, h->flags.p + 16 * (h->fl_parity ^ 1))));
+            h->fl_next_clean = true;
         }
-        if (hier) {  // k_lm_l3 gathered the four words
-            HIPCHK(h, hipMemcpyAsync(h->pin_i, h->flags.p + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        h->counts_on_side = false;
+        if (hier && h->optimistic && !h->timing) {
+            h->counts_on_side = true;   // (a copy on the main stream is a 6 us blit kernel between k_lm_l3 and k_rec_push: it goes over the side stream)
+        } else if (hier) {  // k_lm_l3 gathered the four words
+            HIPCHK(h, hipMemcpyAsync(h->pin_i, h->fl + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         } else {
             HIPCHK(h, hipMemcpyAsync(h->pin_i, h->ent_off.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipMemcpyAsync(h->pin_i + 1, h->new_rank.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->pin_i + 2, h->fl, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         }
         if (h->optimistic && hier) break;   // (no host look here: icm_sweep_finish reads the four words)
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->pin_i[2] && h->hash_slots == 128) {  // a scan with > 96 distinct landmarks: use the larger table from now on
             h->hash_slots = 256;
-            HIPCHK(h, hipMemsetAsync(h->flags.p, 0, 16 * sizeof(int), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->fl, 0, 16 * sizeof(int), h->stream));
             continue;
         }
         break;
@@ -999,7 +1011,7 @@ int icm_sweep_local(icm_handle* h) {
     if (h->optimistic && hier) {
         h->path_used = 1;
         if (h->world > 1)
-            k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, 0.0, 0.0, h->x, edge_first(h), edge_last(h), edge_last2(h), run_scan ? h->new_rank.p + nloc : h->flags.p + 9, h->flags.p);
+            k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, 0.0, 0.0, h->x, edge_first(h), edge_last(h), edge_last2(h), run_scan ? h->new_rank.p + nloc : h->fl + 9, h->fl);
         HIPCHK(h, hipGetLastError());
         return ICM_OK;
     }
@@ -1056,7 +1068,7 @@ static int launch_ghost(icm_handle* h) {
         h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p, gm, gm + 1, gm + 8, h->gh_rot.p, h->ghost_n, gm + 2, gm + 3, 0, kWave);
     k_ghost_moments<<<1, kWave, 0, gs>>>(h->x, (int)h->t_begin - 1, gm, gm + 2, h->gh_st_label.p, h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p,
         h->gh_s2.p, h->gh_rot.p, h->off_sx.p, h->off_sy.p, h->off_n.p,
-        h->stats_all + (size_t)(h->rank - 1) * (size_t)icm_stats_stride(h), L, h->lact0, h->gh_m.p, gm + 8, h->flags.p);
+        h->stats_all + (size_t)(h->rank - 1) * (size_t)icm_stats_stride(h), L, h->lact0, h->gh_m.p, gm + 8, h->fl);
     HIPCHK(h, hipGetLastError());
     if (!h->timing) {   // (icm_sweep_solve makes the main stream wait for it in front of the solve launch)
         HIPCHK(h, hipEventRecord(h->ev_gh1, gs));
@@ -1108,6 +1120,7 @@ int icm_sweep_targets(icm_handle* h) {
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     const int nlab = h->lact0 + (int)h->n_new_loc;
     const bool ghost = h->world > 1 && h->rank > 0;
+    bool ev_map_recorded = false;
     if (h->world > 1) {
         // the neighbours' boundary poses (previous-sweep values) came with their statistics
         const int a = (int)h->t_begin, b = (int)(h->t_begin + h->nloc);
@@ -1121,11 +1134,23 @@ int icm_sweep_targets(icm_handle* h) {
         const size_t msn = (size_t)h->nsuper * (size_t)L;
         double* ro = h->rec_off.p;
         if (h->world > 1)
-            TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p, h->optimistic ? h->flags.p : nullptr)));
+            TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p, h->optimistic ? h->fl : nullptr)));
         if (ghost) {
             int rcg = launch_ghost(h);
             if (rcg) return rcg;
         }
+        // The side stream's work (Mapa.filtrar, the 16-byte counts copy, clearing the matrix) needs the raw map, the flags and
+        // the matrix's last reader -- all done with k_rec_push, not with the moments behind it.  Its start signal is the STOP
+        // EVENT of that launch (hipExtLaunchKernel: the dispatch packet's own completion signal) rather than an event
+        // recorded behind the moments: no marker packet on the main queue between the moments and the solves, and the side
+        // stream -- hence the host's one wait of the sweep, hence the next sweep's launches -- starts a kernel earlier.
+        if (!h->timing) {
+            hipExtLaunchKernelGGL(k_rec_push, dim3(nblocks_threads(nrec)), dim3(kBlock), 0, h->stream, nullptr, h->ev_map, 0,
+                nrec, h->chunk_group, L, (const int*)h->rec_label.p, (const double*)h->ms.p, (const double*)(h->ms.p + msn), (const double*)(h->ms.p + 2 * msn),
+                (const double*)(h->world > 1 ? h->off_sx.p : nullptr), (const double*)(h->world > 1 ? h->off_sy.p : nullptr), (const double*)(h->world > 1 ? h->off_n.p : nullptr),
+                ro, ro + nrec, ro + 2 * (size_t)nrec, 0);
+            ev_map_recorded = true;
+        } else
         TIMED(h, KID_REC_PUSH, (k_rec_push<<<nblocks_threads(nrec), kBlock, 0, h->stream>>>(
             nrec, h->chunk_group, L, h->rec_label.p, h->ms.p, h->ms.p + msn, h->ms.p + 2 * msn,
             h->world > 1 ? h->off_sx.p : nullptr, h->world > 1 ? h->off_sy.p : nullptr, h->world > 1 ? h->off_n.p : nullptr,
@@ -1151,9 +1176,13 @@ int icm_sweep_targets(icm_handle* h) {
     HIPCHK(h, hipGetLastError());
     // The raw map (and, sharded, the ranks' new-landmark counts) is final here: start its
     // download on the copy stream so that Mapa.filtrar on the host overlaps the pose solves.
-    HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
+    if (!ev_map_recorded) HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
     const size_t Ls = (size_t)L;
+    if (h->counts_on_side) {
+        HIPCHK(h, hipMemcpyAsync(h->pin_i, h->fl + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        h->counts_on_side = false;
+    }
     if (h->world > 1)
         for (int r = 0; r < h->world && r < 64; ++r)
             HIPCHK(h, hipMemcpyAsync(h->pin_d + 3 * Ls + 16 + r, h->stats_all + (size_t)r * (size_t)icm_stats_stride(h) + 3 * Ls, sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
@@ -1168,7 +1197,7 @@ int icm_sweep_targets(icm_handle* h) {
         HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
     }
     if (h->optimistic)   // the sweep's flags as every rank sees them (k_stats_prefix folded the other ranks' in)
-        HIPCHK(h, hipMemcpyAsync(h->pin_i + 12, h->flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));   // ([3]: poses outside their reserved staging place)
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 12, h->fl, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));   // ([3]: poses outside their reserved staging place)
     if (h->path_used == 1) {  // next sweep's matrix: cleared here, under the solves (icm_sweep_finish waits for this stream)
         HIPCHK(h, hipMemsetAsync(h->ms.p, 0, 3 * (size_t)h->nsuper * (size_t)L * sizeof(double), h->copy_stream));
         h->ms_clean = true;
@@ -1269,7 +1298,7 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     // the next sweep needs no k_pose_rot launch
     a.rot = h->form == 0 ? h->rot.p : nullptr;
     if (h->form != 0) h->rot_valid = false;   // (the cross-check forms do not keep it)
-    const int* abort = h->optimistic ? h->flags.p : nullptr;
+    const int* abort = h->optimistic ? h->fl : nullptr;
     if (h->world > 1 && h->form != 0)
         FAIL(h, ICM_ERR_UNSUPPORTED, "the per-beam / per-entry cross-check forms of the energy are single-rank only (a shard's ghost pose is solved in moment form)");
     if (h->world > 1 && h->rank > 0 && ((h->t_begin & 1) || h->t_begin < 2 || !h->ghost_uploaded))

@@ -1552,7 +1552,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
                                                   double* __restrict__ y_raw, double* __restrict__ cnt_raw,
                                                   const int* __restrict__ n_ent_dev, int* __restrict__ flags,
                                                   int row_begin = 0, int row_end = -1, const double* __restrict__ carry_in = nullptr,
-                                                  double* __restrict__ carry_out = nullptr, int final = 1) {
+                                                  double* __restrict__ carry_out = nullptr, int final = 1,
+                                                  int* __restrict__ flags_next = nullptr) {
     __shared__ double tot[3][kL3Groups][kWave];
     const int col = threadIdx.x & (kWave - 1), grp = threadIdx.x >> 6;
     const int i = blockIdx.x * kWave + col;
@@ -1563,6 +1564,10 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
         flags[6] = flags[0];
         flags[7] = flags[1];
         flags[2] = lact0 + *n_new_dev > L ? 1 : 0;   // labels beyond the map capacity (the reference's IndexError)
+        // the NEXT sweep's flag block (the sweeps alternate between two): nobody reads it any more -- the sweep before this
+        // one is over, host included -- and clearing it here saves the next sweep a memset launch at its head
+        if (flags_next)
+            for (int q = 0; q < 16; ++q) flags_next[q] = 0;
     }
     // groups are ABSOLUTE row ranges [16 g, 16 g + 16): a sweep that takes the rows in two ranges (cut at a multiple of
     // kL3Rows: pipeline_split_super) adds every column up in the same association as one that takes them at once
