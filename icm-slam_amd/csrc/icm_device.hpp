@@ -192,40 +192,50 @@ constexpr int kMomentCount = 14;
 // two-operand v_fmac_f64 and then has to copy every loop-invariant addend (polynomial
 // coefficient, moment sum) into a scratch register first -- a v_mov_b64 per fma inside the
 // Nelder-Mead loop, ~20 % of an evaluation's instructions.  fnma_ = fma(-a, b, c), fmas_ = fma(a, b, -c).
-__device__ __forceinline__ double fma_(double a, double b, double c) {
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ double fnma_(double a, double b, double c) {
-    double d;
-    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ double fmas_(double a, double b, double c) {
-    double d;
-    asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ double fnma_(double a, double b, double c) { return __builtin_fma(-a, b, c); }
+__device__ __forceinline__ double fmas_(double a, double b, double c) { return __builtin_fma(a, b, -c); }
 
 // sin d and cos d - 1 for |d| <= 0.25 by their Taylor polynomials (truncation < 1e-18), as
 // explicit fused multiply-adds (our own arithmetic: not part of the reference's expression
 // tree that -ffp-contract=off protects).
-__device__ __forceinline__ void small_sincosm1(double d, double& s, double& cm1) {
+// The thirteen coefficients: literals by default (LitTrigK: the compiler materialises each one in front of its fma,
+// a v_mov_b64 per coefficient per evaluation), or held in vector registers for the length of a Nelder-Mead
+// (PinnedTrigK: 26 VGPRs the fold-only solve has to spare; a lone wave pays ~5 cycles for every instruction it
+// issues, copies included).  Same numbers, same operations, same order.
+struct LitTrigK {
+    static constexpr double s6 = -1.0 / 6227020800.0, s5 = 1.0 / 39916800.0, s4 = -1.0 / 362880.0, s3 = 1.0 / 5040.0,
+                            s2 = -1.0 / 120.0, s1 = 1.0 / 6.0;
+    static constexpr double c7 = 1.0 / 87178291200.0, c6 = -1.0 / 479001600.0, c5 = 1.0 / 3628800.0, c4 = -1.0 / 40320.0,
+                            c3 = 1.0 / 720.0, c2 = -1.0 / 24.0, c1 = 0.5;
+};
+struct PinnedTrigK {
+    double s6, s5, s4, s3, s2, s1, c7, c6, c5, c4, c3, c2, c1;
+    __device__ __forceinline__ PinnedTrigK()
+        : s6(LitTrigK::s6), s5(LitTrigK::s5), s4(LitTrigK::s4), s3(LitTrigK::s3), s2(LitTrigK::s2), s1(LitTrigK::s1),
+          c7(LitTrigK::c7), c6(LitTrigK::c6), c5(LitTrigK::c5), c4(LitTrigK::c4), c3(LitTrigK::c3), c2(LitTrigK::c2),
+          c1(LitTrigK::c1) {
+        // (opaque to the optimiser: a value it cannot re-materialise stays in its register)
+        asm volatile("" : "+v"(s6), "+v"(s5), "+v"(s4), "+v"(s3), "+v"(s2), "+v"(s1));
+        asm volatile("" : "+v"(c7), "+v"(c6), "+v"(c5), "+v"(c4), "+v"(c3), "+v"(c2), "+v"(c1));
+    }
+};
+template <class K = LitTrigK>
+__device__ __forceinline__ void small_sincosm1(double d, double& s, double& cm1, const K& k = K()) {
     const double z = d * d;
-    double ps = fma_(z, -1.0 / 6227020800.0, 1.0 / 39916800.0);  // z^6/13!, z^5/11!
-    ps = fma_(z, ps, -1.0 / 362880.0);
-    ps = fma_(z, ps, 1.0 / 5040.0);
-    ps = fma_(z, ps, -1.0 / 120.0);
-    ps = fma_(z, ps, 1.0 / 6.0);
-    s = fnma_(d * z, ps, d);                                     // d - d^3/6 + ...
-    double pc = fma_(z, 1.0 / 87178291200.0, -1.0 / 479001600.0);  // z^7/14!, z^6/12!
-    pc = fma_(z, pc, 1.0 / 3628800.0);
-    pc = fma_(z, pc, -1.0 / 40320.0);
-    pc = fma_(z, pc, 1.0 / 720.0);
-    pc = fma_(z, pc, -1.0 / 24.0);
-    pc = fma_(z, pc, 0.5);
-    cm1 = -(z * pc);                                                        // -d^2/2 + d^4/24 - ...
+    double ps = fma_(z, k.s6, k.s5);  // z^6/13!, z^5/11!
+    ps = fma_(z, ps, k.s4);
+    ps = fma_(z, ps, k.s3);
+    ps = fma_(z, ps, k.s2);
+    ps = fma_(z, ps, k.s1);
+    s = fnma_(d * z, ps, d);          // d - d^3/6 + ...
+    double pc = fma_(z, k.c7, k.c6);  // z^7/14!, z^6/12!
+    pc = fma_(z, pc, k.c5);
+    pc = fma_(z, pc, k.c4);
+    pc = fma_(z, pc, k.c3);
+    pc = fma_(z, pc, k.c2);
+    pc = fma_(z, pc, k.c1);
+    cm1 = -(z * pc);                  // -d^2/2 + d^4/24 - ...
 }
 
 // Derived sums of the isotropic form (Q0 == Q1): with X, Y the two quadratic forms below,
@@ -382,9 +392,10 @@ __device__ __forceinline__ void make_fold(const SolveCtx& c, const PoseMoments& 
     f.dlim = (iso && kmax < 3.0) ? fmin(0.25, 3.0 - kmax) : -1.0;   // (NaN anywhere -> -1: the term-by-term form)
 }
 
-__device__ __forceinline__ double pose_energy_folded(const PoseFold& f, double px, double py, double dl) {
+template <class K = LitTrigK>
+__device__ __forceinline__ double pose_energy_folded(const PoseFold& f, double px, double py, double dl, const K& k = K()) {
     double al, be;
-    small_sincosm1(dl, be, al);
+    small_sincosm1(dl, be, al, k);
     const double dx = px - f.pox, dy = py - f.poy;
     const double l1 = fma_(f.B1, al, fma_(f.B2, be, f.B0));
     const double l2 = fma_(f.B1, be, fnma_(f.B2, al, f.C0));
@@ -398,10 +409,12 @@ __device__ __forceinline__ double pose_energy_folded(const PoseFold& f, double p
 // stored by that kernel but marked, and the fix-up launch behind it solves it with pose_energy_moments() below
 // (folded where valid, term by term elsewhere): the main kernel then keeps neither the context nor the moment
 // sums alive across the Nelder-Mead loop -- thirteen coefficients, no scratch.
-__device__ __forceinline__ double pose_energy_fold_only(const PoseFold& f, double px, double py, double th, bool& ok) {
+template <class K = LitTrigK>
+__device__ __forceinline__ double pose_energy_fold_only(const PoseFold& f, double px, double py, double th, bool& ok,
+                                                        const K& k = K()) {
     const double dl = th - f.tho;
     ok = fabs(dl) <= f.dlim;   // (NaN -> false)
-    return pose_energy_folded(f, px, py, dl);
+    return pose_energy_folded(f, px, py, dl, k);
 }
 
 __device__ __forceinline__ double pose_energy_moments(const SolveCtx& c, const PoseMoments& m, const PoseFold& f, double px,
@@ -543,6 +556,71 @@ __device__ __forceinline__ void sort4(Vtx& v0, Vtx& v1, Vtx& v2, Vtx& v3) {
     cswap(v0, v1);
 }
 
+// Sorted insertion of one vertex into the simplex (v0 <= v1 <= v2 by f; v3, the worst, is dropped) for the lanes of
+// `ins`; the vertex is t for the lanes of `use_t`, else r.  Spelled out as whole-vertex moves under lane masks -- one
+// v_mov_b64 per coordinate, exec set per move -- because the compiler's forms of it (three conditional swaps behind two
+// selects, or one `if` per move, each with its own branch) cost half as much again: 32 moves, 3 compares and 10 scalar
+// instructions here against 16 selects, 41 moves and the swaps' exec bookkeeping.  Hazards (gfx950 = gfx9 rules): a
+// VALU-written SGPR read by the SALU and an SALU-written exec used by the VALU are interlocked by the hardware.
+//   g_k = ins & (n.f < v_k.f)   (g0 => g1 => g2 because the simplex is sorted)
+//   g2: v3 <- v2;  g1: v2 <- v1;  g0: v1 <- v0, v0 <- n;  g1 & !g0: v1 <- n;  g2 & !g1: v2 <- n;  ins & !g2: v3 <- n
+__device__ __forceinline__ void insert_vertex(Vtx& v0, Vtx& v1, Vtx& v2, Vtx& v3, Vtx r, const Vtx& t, bool use_t, bool ins) {
+    const unsigned long long m_t = __builtin_amdgcn_ballot_w64(use_t), m_ins = __builtin_amdgcn_ballot_w64(ins);
+    unsigned long long sv, m2, m1, m0;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[mt]\n\t"
+        "v_mov_b64 %[rx], %[tx]\n\t"
+        "v_mov_b64 %[ry], %[ty]\n\t"
+        "v_mov_b64 %[rt], %[tt]\n\t"
+        "v_mov_b64 %[rf], %[tf]\n\t"
+        "s_mov_b64 exec, %[mi]\n\t"
+        "v_cmp_lt_f64 %[m2], %[rf], %[f2]\n\t"
+        "v_cmp_lt_f64 %[m1], %[rf], %[f1]\n\t"
+        "v_cmp_lt_f64 %[m0], %[rf], %[f0]\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "v_mov_b64 %[x3], %[x2]\n\t"
+        "v_mov_b64 %[y3], %[y2]\n\t"
+        "v_mov_b64 %[t3], %[t2]\n\t"
+        "v_mov_b64 %[f3], %[f2]\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "v_mov_b64 %[x2], %[x1]\n\t"
+        "v_mov_b64 %[y2], %[y1]\n\t"
+        "v_mov_b64 %[t2], %[t1]\n\t"
+        "v_mov_b64 %[f2], %[f1]\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "v_mov_b64 %[x1], %[x0]\n\t"
+        "v_mov_b64 %[y1], %[y0]\n\t"
+        "v_mov_b64 %[t1], %[t0]\n\t"
+        "v_mov_b64 %[f1], %[f0]\n\t"
+        "v_mov_b64 %[x0], %[rx]\n\t"
+        "v_mov_b64 %[y0], %[ry]\n\t"
+        "v_mov_b64 %[t0], %[rt]\n\t"
+        "v_mov_b64 %[f0], %[rf]\n\t"
+        "s_andn2_b64 exec, %[m1], %[m0]\n\t"
+        "v_mov_b64 %[x1], %[rx]\n\t"
+        "v_mov_b64 %[y1], %[ry]\n\t"
+        "v_mov_b64 %[t1], %[rt]\n\t"
+        "v_mov_b64 %[f1], %[rf]\n\t"
+        "s_andn2_b64 exec, %[m2], %[m1]\n\t"
+        "v_mov_b64 %[x2], %[rx]\n\t"
+        "v_mov_b64 %[y2], %[ry]\n\t"
+        "v_mov_b64 %[t2], %[rt]\n\t"
+        "v_mov_b64 %[f2], %[rf]\n\t"
+        "s_andn2_b64 exec, %[mi], %[m2]\n\t"
+        "v_mov_b64 %[x3], %[rx]\n\t"
+        "v_mov_b64 %[y3], %[ry]\n\t"
+        "v_mov_b64 %[t3], %[rt]\n\t"
+        "v_mov_b64 %[f3], %[rf]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(sv), [m2] "=&s"(m2), [m1] "=&s"(m1), [m0] "=&s"(m0),
+          [rx] "+v"(r.x), [ry] "+v"(r.y), [rt] "+v"(r.t), [rf] "+v"(r.f),
+          [x0] "+v"(v0.x), [y0] "+v"(v0.y), [t0] "+v"(v0.t), [f0] "+v"(v0.f),
+          [x1] "+v"(v1.x), [y1] "+v"(v1.y), [t1] "+v"(v1.t), [f1] "+v"(v1.f),
+          [x2] "+v"(v2.x), [y2] "+v"(v2.y), [t2] "+v"(v2.t), [f2] "+v"(v2.f),
+          [x3] "+v"(v3.x), [y3] "+v"(v3.y), [t3] "+v"(v3.t), [f3] "+v"(v3.f)
+        : [tx] "v"(t.x), [ty] "v"(t.y), [tt] "v"(t.t), [tf] "v"(t.f), [mt] "s"(m_t), [mi] "s"(m_ins));
+}
+
 __device__ __forceinline__ double amax3(const Vtx& a, const Vtx& b) {
     return fmax(fmax(fabs(a.x - b.x), fabs(a.y - b.y)), fabs(a.t - b.t));
 }
@@ -558,13 +636,16 @@ __device__ __forceinline__ double amax3(const Vtx& a, const Vtx& b) {
 // entered shrink loop, and one for the four initial vertices.  Four inlined copies of the
 // energy in total, and no per-evaluation state dispatch.
 // out = {x, y, theta, f, nit, nfev}.
-// `stop` (optional): a per-lane predicate looked at once per iteration beside SciPy's own termination test; a lane
-// for which it holds leaves the loop (its result is discarded by the caller: fold-only solves).
+// `stop` (optional): a per-lane predicate looked at once in front of the loop and once at the end of every iteration,
+// beside SciPy's own termination test: "did anything since the last look disqualify this solve?".  A lane for which it
+// holds leaves the loop and the function returns true for it (its result is discarded by the caller: fold-only
+// solves).  The predicate is asked about the time since the last look so that nothing of it is carried around the
+// loop (a carried flag is a byte in a vector register and five instructions an iteration).
 struct NeverStop {
     __device__ __forceinline__ bool operator()() const { return false; }
 };
 template <class F, class S = NeverStop>
-__device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double st, double out[6], S stop = S()) {
+__device__ __forceinline__ bool nelder_mead3(F f, double sx, double sy, double st, double out[6], S stop = S()) {
     const int maxfun = 600, maxiter = 600;
     const double xatol = 1e-3, fatol = 1e-4;
     const double grow = 1 + 0.05;
@@ -594,10 +675,18 @@ __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double s
     // branches (a third of the instructions of an iteration).  Same arithmetic, same decisions:
     //   2 xbar - x_w           = fma(2, xbar, -x_w)        (2 xbar is exact)
     //   ca xbar + cb x_w       = fma(cb, x_w, ca xbar)     (cb = -2, -0.5, 0.5: cb x_w is exact)
-    while (nfev < maxfun && it < maxiter) {
+    // ONE loop condition, formed at the bottom of the iteration (and once in front of the loop) from everything that
+    // ends the solve -- SciPy's termination test, the budgets, an aborted iteration, `stop` -- as lane-mask algebra:
+    // the loop costs one exec update per iteration instead of a nest of break blocks (a lone wave pays ~5 cycles for
+    // every scalar instruction too, `tools/ubench_issue.hip`).
+    auto settled = [&]() {
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
-        if ((dx <= xatol && df <= fatol) || stop()) break;
+        return (dx <= xatol) & (df <= fatol);
+    };
+    bool stopped = stop();
+    bool go = !(settled() | stopped);   // (nfev = 4 < maxfun, it = 1 < maxiter)
+    while (go) {
         const double bx = div3((v0.x + v1.x) + v2.x);
         const double by = div3((v0.y + v1.y) + v2.y);
         const double bt = div3((v0.t + v1.t) + v2.t);
@@ -623,10 +712,10 @@ __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double s
         const bool aborted0 = need2 & !can2;
         const bool use_t = can2 & take_t;
         const bool keep = shrink | aborted0;
-        {
-            const double nx = use_t ? t.x : r.x, ny = use_t ? t.y : r.y, nt = use_t ? t.t : r.t, nf = use_t ? t.f : r.f;
-            v3.x = keep ? v3.x : nx; v3.y = keep ? v3.y : ny; v3.t = keep ? v3.t : nt; v3.f = keep ? v3.f : nf;
-        }
+        // The vertex that enters (the second point where it was taken, else the reflection) goes straight to its place:
+        // numpy's insertion argsort moves it left past the strictly larger ones, i.e. the vertices above it shift up by
+        // one (`keep`: a shrink or an aborted iteration leaves the simplex to the block below).
+        insert_vertex(v0, v1, v2, v3, r, t, use_t, !keep);
         bool aborted = aborted0;
         if (__builtin_expect(shrink, 0)) {
 #pragma unroll 1
@@ -643,18 +732,14 @@ __device__ __forceinline__ void nelder_mead3(F f, double sx, double sy, double s
                 if (!go) { aborted = true; break; }
             }
             sort4(v0, v1, v2, v3);
-        } else {
-            // only the last vertex changed: numpy's (insertion) argsort moves it left past the
-            // strictly larger ones
-            cswap(v2, v3);
-            cswap(v1, v2);
-            cswap(v0, v1);
         }
-        if (aborted) break;
-        ++it;
+        it += aborted ? 0 : 1;
+        stopped = stop();
+        go = !aborted & (nfev < maxfun) & (it < maxiter) & !(settled() | stopped);
     }
     out[0] = v0.x; out[1] = v0.y; out[2] = v0.t; out[3] = v0.f;
     out[4] = (double)it; out[5] = (double)nfev;
+    return stopped;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -687,7 +772,7 @@ __device__ __forceinline__ bool quad_any(bool b) {
 
 // (`stop` must be uniform over the quad: its four lanes take every decision together)
 template <class F, class S = NeverStop>
-__device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, double st, int role, double out[6], S stop = S()) {
+__device__ __forceinline__ bool nelder_mead3_quad(F f, double sx, double sy, double st, int role, double out[6], S stop = S()) {
     const int maxfun = 600, maxiter = 600;
     const double xatol = 1e-3, fatol = 1e-4;
     const double grow = 1 + 0.05;
@@ -711,10 +796,12 @@ __device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, dou
     // point r of an iteration = ca[r] * xbar + cb[r] * sim[-1]
     const double ca = role == 0 ? 2.0 : (role == 1 ? 3.0 : (role == 2 ? 1.5 : 0.5));
     const double cb = role == 0 ? -1.0 : (role == 1 ? -2.0 : (role == 2 ? -0.5 : 0.5));
+    bool stopped = false;
     while (nfev < maxfun && it < maxiter) {
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
-        if ((dx <= xatol && df <= fatol) || stop()) break;
+        stopped = stop();
+        if ((dx <= xatol && df <= fatol) || stopped) break;
         const double bx = div3((v0.x + v1.x) + v2.x);
         const double by = div3((v0.y + v1.y) + v2.y);
         const double bt = div3((v0.t + v1.t) + v2.t);
@@ -781,8 +868,10 @@ __device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, dou
         if (aborted) break;
         ++it;
     }
+    stopped = stopped | stop();   // (the evaluations of an iteration that ended on the budgets)
     out[0] = v0.x; out[1] = v0.y; out[2] = v0.t; out[3] = v0.f;
     out[4] = (double)it; out[5] = (double)nfev;
+    return stopped;
 }
 
 }  // namespace icm

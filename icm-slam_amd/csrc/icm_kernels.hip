@@ -2502,17 +2502,17 @@ __device__ __forceinline__ bool solve_pose_in(const SolveArgs& a, int tg, const 
     }
     double out[6];
     if (FOLD) {
-        bool inside = true;   // every evaluation so far stayed inside the folded form's range (quad: of the whole quad)
+        bool left = false;    // an evaluation since the Nelder-Mead last asked left the folded form's range (quad: of the whole quad)
+        const PinnedTrigK trig;
         auto ef = [&](double px, double py, double th) {
             bool ok;
-            const double e = pose_energy_fold_only(f, px, py, th, ok);
-            inside &= QUAD ? !quad_any(!ok) : ok;
+            const double e = pose_energy_fold_only(f, px, py, th, ok, trig);
+            left |= QUAD ? quad_any(!ok) : !ok;
             return e;
         };
-        auto stop = [&]() { return !inside; };
-        if (QUAD) nelder_mead3_quad(ef, sx, sy, st, role, out, stop);
-        else nelder_mead3(ef, sx, sy, st, out, stop);
-        if (!inside) return false;
+        auto stop = [&]() { const bool l = left; left = false; return l; };
+        const bool stopped = QUAD ? nelder_mead3_quad(ef, sx, sy, st, role, out, stop) : nelder_mead3(ef, sx, sy, st, out, stop);
+        if (stopped) return false;
     } else if (QUAD) {
         nelder_mead3_quad([&](double px, double py, double th) { return pose_energy_moments(c, m, f, px, py, th); }, sx, sy, st, role, out);
     } else {
