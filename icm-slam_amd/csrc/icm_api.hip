@@ -142,7 +142,6 @@ struct icm_handle {
     int* fl = nullptr;        // this sweep's block of 16 flag / counter words: the sweeps alternate between the two halves of `flags`,
     int fl_parity = 0;        //   and k_lm_l3 clears the other half for the next sweep (no memset launch at a sweep's head)
     bool fl_next_clean = false;
-    bool counts_on_side = false;   // this sweep's 16-byte counts-and-flags copy goes over the side stream (icm_sweep_targets)
     int cu_count = 256;       // compute units of the device (icm_create)
     int assoc_wave_wgs = 0;   // phase A: four poses per 256-thread workgroup (0, default) or one-wave workgroups (1): measured equal
     int assoc_wg_per_cu = 0;  // phase A on persistent waves: workgroups per CU; 0 (default): one short-lived wave per pose
@@ -207,6 +206,7 @@ struct icm_handle {
     bool opt_req = false;      // asked for: by icm_sweep_classic for its first attempt, by icm_set_optimistic for the phase calls
     DevBuf<double> rot;   // (cos, sin)(theta - pi/2) per pose of the shard, refreshed at the start of every sweep (k_pose_rot)
     hipEvent_t ev_map = nullptr, ev_copied = nullptr;
+    bool map_ev_in_local = false;   // this sweep's ev_map is the stop event of k_lm_l3 (icm_sweep_local)
     bool map_copy_pending = false;
 };
 
@@ -834,6 +834,7 @@ static FiltrarArgs filtrar_args(icm_handle* h) {
     fa.lab = h->fl_lab.p; fa.comp = h->fl_comp.p; fa.csize = h->fl_csize.p; fa.isl = h->fl_isl.p; fa.rank = h->fl_rank.p;
     fa.mapx = h->mapx.p; fa.mapy = h->mapy.p; fa.counts_new = h->counts_new.p;
     fa.gpar = h->gpar.p; fa.g_cell = h->g_cell.p; fa.g_lm = h->g_lm.p; fa.info = h->fl_info.p;
+    fa.info_host = nullptr;
     return fa;
 }
 
@@ -850,10 +851,11 @@ static void launch_grid_chain(icm_handle* h, hipStream_t fs, const FiltrarArgs& 
 }
 
 // Mapa.filtrar + the search grid of the refined map, queued on `fs` (no host involvement).
-static int launch_filtrar(icm_handle* h, hipStream_t fs, bool guarded = false) {
+static int launch_filtrar(icm_handle* h, hipStream_t fs, bool guarded = false, int* info_host = nullptr) {
     const int L = (int)h->cfg.L;
     FiltrarArgs fa = filtrar_args(h);
     if (guarded) fa.sweep_flags = h->fl;   // queued without a host look at the sweep's flags: the kernels look themselves
+    fa.info_host = info_host;              // (a sweep: the outcome goes straight into the host's mapped block)
     const int nb = std::min(kFlMaxBlocks, (L + kFB - 1) / kFB);
     const int chunk = ((L + nb - 1) / nb + kFB - 1) / kFB * kFB;
     TIMED(h, KID_FILTRAR, (k_fl_count<<<nb, kFB, 0, fs>>>(fa, chunk)));
@@ -963,6 +965,7 @@ int icm_sweep_local(icm_handle* h) {
         } else {
             if (dbg) ASSOC_GROUP_HS(false, true); else ASSOC_GROUP_HS(false, false);
         }
+        h->map_ev_in_local = false;
         if (!run_scan && ++h->scan_epoch == 0u) ++h->scan_epoch;   // (tag 0 = never written)
         if (run_scan) {
             TIMED(h, KID_SCAN, (k_scan_tiles<<<ntiles, kBlock, 0, h->stream>>>(h->nent.p, h->isnew.p, h->ent_off.p, h->new_rank.p, h->scan_tot.p, nloc)));
@@ -983,12 +986,25 @@ int icm_sweep_local(icm_handle* h) {
                 h->nchunks, h->chunk_group, L, h->rec_label.p, h->rec_s.p, h->rec_s.p + nrec, h->rec_s.p + 2 * (size_t)nrec,
                 h->rec_off.p, h->rec_off.p + nrec, h->rec_off.p + 2 * (size_t)nrec, ms, ms + msn, ms + 2 * msn, h->fl)));
             double* stats_mine = h->world > 1 ? stats_slot(h) : nullptr;
+            h->map_ev_in_local = false;
+            if (h->optimistic && !h->timing) {
+                // A sweep queued whole.  The four words the host reads at its one wait of the sweep (and, single rank, the
+                // sweep's flags) go straight into its mapped block -- no copy launch on any stream -- and with a single rank the
+                // raw map is final with this launch: its STOP EVENT (hipExtLaunchKernel: the dispatch packet's own completion
+                // signal, no marker packet on the queue) starts the side stream's Mapa.filtrar, a kernel earlier than the end
+                // of k_rec_push.
+                const bool map_final = h->world == 1;
+                hipExtLaunchKernelGGL(k_lm_l3, dim3((L + kWave - 1) / kWave), dim3(kBlock), 0, h->stream, nullptr, map_final ? h->ev_map : nullptr, 0,
+                    h->nsuper, L, h->lact0, (const int*)(run_scan ? h->new_rank.p + nloc : h->fl + 9), ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p,
+                    (const int*)(run_scan ? h->ent_off.p + nloc : h->fl + 8), h->fl, 0, -1, (const double*)nullptr, (double*)nullptr, 1,
+                    h->flags.p + 16 * (h->fl_parity ^ 1), h->pin_i_dev, map_final ? 1 : 0);
+                h->map_ev_in_local = map_final;
+            } else
             TIMED(h, KID_LM_L3, (k_lm_l3<<<(L + kWave - 1) / kWave, kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, run_scan ? h->new_rank.p + nloc : h->fl + 9, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p, run_scan ? h->ent_off.p + nloc : h->fl + 8, h->fl, 0, -1, nullptr, nullptr, 1, h->flags.p + 16 * (h->fl_parity ^ 1))));
             h->fl_next_clean = true;
         }
-        h->counts_on_side = false;
         if (hier && h->optimistic && !h->timing) {
-            h->counts_on_side = true;   // (a copy on the main stream is a 6 us blit kernel between k_lm_l3 and k_rec_push: it goes over the side stream)
+            // (k_lm_l3 wrote the four words into the host's block itself)
         } else if (hier) {  // k_lm_l3 gathered the four words
             HIPCHK(h, hipMemcpyAsync(h->pin_i, h->fl + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         } else {
@@ -1139,12 +1155,15 @@ int icm_sweep_targets(icm_handle* h) {
             int rcg = launch_ghost(h);
             if (rcg) return rcg;
         }
-        // The side stream's work (Mapa.filtrar, the 16-byte counts copy, clearing the matrix) needs the raw map, the flags and
-        // the matrix's last reader -- all done with k_rec_push, not with the moments behind it.  Its start signal is the STOP
-        // EVENT of that launch (hipExtLaunchKernel: the dispatch packet's own completion signal) rather than an event
+        // The side stream's work (Mapa.filtrar) needs the raw map and the flags -- not the moments behind.  Its start signal is
+        // the STOP EVENT of a launch (hipExtLaunchKernel: the dispatch packet's own completion signal) rather than an event
         // recorded behind the moments: no marker packet on the main queue between the moments and the solves, and the side
-        // stream -- hence the host's one wait of the sweep, hence the next sweep's launches -- starts a kernel earlier.
-        if (!h->timing) {
+        // stream -- hence the host's one wait of the sweep, hence the next sweep's launches -- starts early: with k_lm_l3
+        // where the raw map is final there (single rank, icm_sweep_local), else with this launch.  (A stop event costs the
+        // main queue ~5 us behind its launch: one per sweep, not two -- the matrix is cleared by k_pose_moments_h, not by a
+        // memset behind an event of k_rec_push.)
+        if (h->map_ev_in_local) ev_map_recorded = true;
+        if (!h->timing && !h->map_ev_in_local) {
             hipExtLaunchKernelGGL(k_rec_push, dim3(nblocks_threads(nrec)), dim3(kBlock), 0, h->stream, nullptr, h->ev_map, 0,
                 nrec, h->chunk_group, L, (const int*)h->rec_label.p, (const double*)h->ms.p, (const double*)(h->ms.p + msn), (const double*)(h->ms.p + 2 * msn),
                 (const double*)(h->world > 1 ? h->off_sx.p : nullptr), (const double*)(h->world > 1 ? h->off_sy.p : nullptr), (const double*)(h->world > 1 ? h->off_n.p : nullptr),
@@ -1158,7 +1177,8 @@ int icm_sweep_targets(icm_handle* h) {
         TIMED(h, KID_POSE_MOMENTS, (k_pose_moments_h<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(
             h->x, h->x0.p, (int)h->t_begin, nloc, h->st_off.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p,
             h->pre_x.p, h->pre_y.p, h->pre_n.p, h->chunk_poses,
-            ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr, 0, -1, h->rot.p)));
+            ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr, 0, -1, h->rot.p, h->ms.p, 3 * msn)));
+        h->ms_clean = true;   // (next sweep's matrix)
     } else if (h->world > 1) {
         TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
         if (ghost) {
@@ -1179,29 +1199,21 @@ int icm_sweep_targets(icm_handle* h) {
     if (!ev_map_recorded) HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
     const size_t Ls = (size_t)L;
-    if (h->counts_on_side) {
-        HIPCHK(h, hipMemcpyAsync(h->pin_i, h->fl + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
-        h->counts_on_side = false;
-    }
     if (h->world > 1)
         for (int r = 0; r < h->world && r < 64; ++r)
             HIPCHK(h, hipMemcpyAsync(h->pin_d + 3 * Ls + 16 + r, h->stats_all + (size_t)r * (size_t)icm_stats_stride(h) + 3 * Ls, sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
     if (h->gpu_filtrar) {
         hipStream_t fs = h->timing ? h->stream : h->copy_stream;   // (timing: serialised on the main stream so that the events bracket it)
-        int rc = launch_filtrar(h, fs, h->optimistic);
+        int rc = launch_filtrar(h, fs, h->optimistic, h->pin_i_dev + 8);
         if (rc) return rc;
         if (h->timing) {
             HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
         }
-        HIPCHK(h, hipMemcpyAsync(h->pin_i + 8, h->fl_info.p, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));
+        // (k_fl_finalize wrote its three words into the host's block itself: no copy launch behind the chain)
     }
-    if (h->optimistic)   // the sweep's flags as every rank sees them (k_stats_prefix folded the other ranks' in)
-        HIPCHK(h, hipMemcpyAsync(h->pin_i + 12, h->fl, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));   // ([3]: poses outside their reserved staging place)
-    if (h->path_used == 1) {  // next sweep's matrix: cleared here, under the solves (icm_sweep_finish waits for this stream)
-        HIPCHK(h, hipMemsetAsync(h->ms.p, 0, 3 * (size_t)h->nsuper * (size_t)L * sizeof(double), h->copy_stream));
-        h->ms_clean = true;
-    }
+    if (h->optimistic && !h->map_ev_in_local)   // the sweep's flags as every rank sees them (k_stats_prefix folded the other ranks' in;
+        HIPCHK(h, hipMemcpyAsync(h->pin_i + 12, h->fl, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));   // single rank: k_lm_l3 wrote them)  ([3]: poses outside their reserved staging place)
     HIPCHK(h, hipEventRecord(h->ev_copied, h->copy_stream));
     h->map_copy_pending = true;
     return ICM_OK;
@@ -1850,7 +1862,6 @@ int icm_filtrar(const icm_config* cfg, const double* y, const double* counts, in
     return filtrar_host(*cfg, y, counts, lact, y_out, counts_out, lact_out, g_create_err);
 }
 
-static int launch_filtrar(icm_handle* h, hipStream_t fs, bool guarded);
 static int launch_filtrar_merge(icm_handle* h, hipStream_t fs, int n);
 
 int icm_filtrar_device(icm_handle* h, const double* y, const double* counts, int64_t lact, double* y_out,

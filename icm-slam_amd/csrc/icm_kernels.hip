@@ -1553,7 +1553,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
                                                   const int* __restrict__ n_ent_dev, int* __restrict__ flags,
                                                   int row_begin = 0, int row_end = -1, const double* __restrict__ carry_in = nullptr,
                                                   double* __restrict__ carry_out = nullptr, int final = 1,
-                                                  int* __restrict__ flags_next = nullptr) {
+                                                  int* __restrict__ flags_next = nullptr, int* __restrict__ host_words = nullptr,
+                                                  int host_flags = 0) {
     __shared__ double tot[3][kL3Groups][kWave];
     const int col = threadIdx.x & (kWave - 1), grp = threadIdx.x >> 6;
     const int i = blockIdx.x * kWave + col;
@@ -1568,6 +1569,13 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
         // one is over, host included -- and clearing it here saves the next sweep a memset launch at its head
         if (flags_next)
             for (int q = 0; q < 16; ++q) flags_next[q] = 0;
+        // the same words straight into the host's (mapped, pinned) block: no 16-byte copy launch -- a 5 us blit kernel -- on
+        // any stream; host_flags: the sweep's flags as well (single rank: nothing behind this launch changes them)
+        if (host_words) {
+            for (int q = 0; q < 4; ++q) host_words[q] = flags[4 + q];
+            if (host_flags)
+                for (int q = 0; q < 4; ++q) host_words[12 + q] = flags[q];
+        }
     }
     // groups are ABSOLUTE row ranges [16 g, 16 g + 16): a sweep that takes the rows in two ranges (cut at a multiple of
     // kL3Rows: pipeline_split_super) adds every column up in the same association as one that takes them at once
@@ -1719,6 +1727,7 @@ struct FiltrarArgs {
     int* g_cell;
     LmRec* g_lm;
     int* info;
+    int* info_host = nullptr;   // nullable: the host's mapped copy of info[0..2] (k_fl_finalize writes both)
 };
 
 __device__ __forceinline__ int block_exscan_1024(int v, int* wsum, int& total) {
@@ -1930,11 +1939,13 @@ __global__ __launch_bounds__(kBlock) void k_fl_pairs(FiltrarArgs a) {
 }
 
 __global__ __launch_bounds__(kFB) void k_fl_finalize(FiltrarArgs a) {
+    // (info_host: the host's mapped copy of the three words, written here instead of copied behind the chain)
     if (a.st->abort) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             a.info[0] = 0;
             a.info[1] = 3;   // nothing touched: the host re-runs the sweep
             a.info[2] = 0;
+            if (a.info_host) { a.info_host[0] = 0; a.info_host[1] = 3; a.info_host[2] = 0; }
         }
         return;
     }
@@ -1945,6 +1956,7 @@ __global__ __launch_bounds__(kFB) void k_fl_finalize(FiltrarArgs a) {
         a.info[0] = n;
         a.info[1] = host ? 2 : (merge ? 1 : 0);
         a.info[2] = a.st->close;
+        if (a.info_host) { a.info_host[0] = n; a.info_host[1] = host ? 2 : (merge ? 1 : 0); a.info_host[2] = a.st->close; }
     }
     if (host || merge) {
         // the search structures hold the raw survivors (a consistent grid: k_neigh_table, queued behind,
@@ -2294,7 +2306,14 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
                                                            const double* __restrict__ off_x, const double* __restrict__ off_y,
                                                            const double* __restrict__ off_n, double* __restrict__ pose_m,
                                                            double2* __restrict__ tgt_out, int tl_begin = 0, int tl_end = -1,
-                                                           const double* __restrict__ rot = nullptr) {
+                                                           const double* __restrict__ rot = nullptr,
+                                                           double* __restrict__ zero_out = nullptr, size_t zero_n = 0) {
+    // (zero_out: the [superchunk x L] matrix, whose last reader -- k_rec_push -- is the launch in front of this one: cleared
+    // here for the next sweep, a store per thread, instead of by a memset launch behind an event of its own)
+    if (zero_out) {
+        const size_t nthr = (size_t)gridDim.x * kBlock;
+        for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < zero_n; q += nthr) zero_out[q] = 0.0;
+    }
     const int sub = threadIdx.x & 15;
     const int tl = tl_begin + ((blockIdx.x * kBlock + threadIdx.x) >> 4);   // poses [tl_begin, tl_end)
     const bool live = tl < (tl_end < 0 ? nloc : tl_end);
