@@ -156,7 +156,7 @@ struct icm_handle {
     bool ghost_pending = false;   // the ghost chain of this sweep is queued on the solve stream (ev_gh1)
     int fused_spin_limit = 1 << 17;   // polls (x ~0.2 us) an even wave waits for its odd neighbours before deferring
     int fuse_colours = 1;    // 1: both colours of an unsharded red-black sweep in one launch (k_solve_m_fused)
-    bool ms_clean = false;   // the [superchunk x L] matrix is zero (cleared on the side stream under the solves)
+    bool ms_clean = false;   // the [superchunk x L] matrix is zero (cleared by the last fused solve launch, launch_fused_solve)
     int entry_path = -1;     // -1 automatic, 0 sort-based pipeline, 1 hierarchical (falls back when a table overflows)
     bool hier_ok = true;     // cleared by an overflow until the next icm_set_state
     int path_used = 0;       // pipeline of the last sweep: 0 sort-based, 1 hierarchical
@@ -1160,8 +1160,8 @@ int icm_sweep_targets(icm_handle* h) {
         // recorded behind the moments: no marker packet on the main queue between the moments and the solves, and the side
         // stream -- hence the host's one wait of the sweep, hence the next sweep's launches -- starts early: with k_lm_l3
         // where the raw map is final there (single rank, icm_sweep_local), else with this launch.  (A stop event costs the
-        // main queue ~5 us behind its launch: one per sweep, not two -- the matrix is cleared by k_pose_moments_h, not by a
-        // memset behind an event of k_rec_push.)
+        // main queue ~5 us behind its launch: one per sweep, not two -- the matrix is cleared by the solve launch's waiting
+        // even waves, launch_fused_solve, not by a memset behind an event of k_rec_push.)
         if (h->map_ev_in_local) ev_map_recorded = true;
         if (!h->timing && !h->map_ev_in_local) {
             hipExtLaunchKernelGGL(k_rec_push, dim3(nblocks_threads(nrec)), dim3(kBlock), 0, h->stream, nullptr, h->ev_map, 0,
@@ -1177,8 +1177,7 @@ int icm_sweep_targets(icm_handle* h) {
         TIMED(h, KID_POSE_MOMENTS, (k_pose_moments_h<<<nblocks_threads((int64_t)nloc * 16), kBlock, 0, h->stream>>>(
             h->x, h->x0.p, (int)h->t_begin, nloc, h->st_off.p, h->nent.p, h->ent_off.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->pose_s2.p,
             h->pre_x.p, h->pre_y.p, h->pre_n.p, h->chunk_poses,
-            ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr, 0, -1, h->rot.p, h->ms.p, 3 * msn)));
-        h->ms_clean = true;   // (next sweep's matrix)
+            ro, ro + nrec, ro + 2 * (size_t)nrec, h->pose_m.p, h->assoc_kept ? h->tgt.p : nullptr, 0, -1, h->rot.p)));
     } else if (h->world > 1) {
         TIMED(h, KID_STATS_PREFIX, (k_stats_prefix<<<nblocks_threads(L), kBlock, 0, h->stream>>>(h->stats_all, (int)icm_stats_stride(h), h->rank, h->world, L, h->lact0, h->off_sx.p, h->off_sy.p, h->off_n.p, h->y_raw.p, h->cnt_raw.p)));
         if (ghost) {
@@ -1273,7 +1272,12 @@ static int launch_fused_solve(icm_handle* h, SolveArgs a, SolveSeg g, hipStream_
     const bool iso = h->cfg.Q[0] == h->cfg.Q[1] && h->cfg.R[0] == h->cfg.R[1];
     const bool fold = h->fold_mode < 0 ? iso : h->fold_mode == 1;
     const int nb2 = nblocks_waves(2 * nwv), nb1 = nblocks_waves(nwv);
-#define FUSED(Q, F) TIMED(h, KID_SOLVE, (k_solve_m_fused<Q, F><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred)))
+    // phase B's matrix, cleared for the next sweep by the launch's waiting even waves (when that is a few dozen stores per
+    // lane; else, and after any other solve launch, the next sweep clears it itself: ms_clean)
+    const size_t zn = h->path_used == 1 && !h->ms_clean ? 3 * (size_t)h->nsuper * (size_t)h->cfg.L : 0;
+    const bool zero_here = zn > 0 && zn <= (size_t)nwv * kWave * 64 && zn < (1ull << 32);
+    double* const zo = zero_here ? h->ms.p : nullptr;
+#define FUSED(Q, F) TIMED(h, KID_SOLVE, (k_solve_m_fused<Q, F><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred, zo, (unsigned)(zero_here ? zn : 0))))
 #define FIX(Q, EVEN) TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_fix<Q><<<nb1, kBlock, 0, st>>>(a, g, nwv, EVEN, deferred, h->solve_counts.p)))
     if (quad) {
         if (fold) { FUSED(true, true); FIX(true, 0); } else FUSED(true, false);
@@ -1284,6 +1288,7 @@ static int launch_fused_solve(icm_handle* h, SolveArgs a, SolveSeg g, hipStream_
     }
 #undef FUSED
 #undef FIX
+    if (zero_here) h->ms_clean = true;
     HIPCHK(h, hipGetLastError());
     return ICM_OK;
 }

@@ -311,14 +311,24 @@ struct GridParams {  // device resident: written by the host (icm_set_state) or 
 // Everything a beam landing in one cell can be matched to: the landmarks of the cell's 3x3
 // neighbourhood, inline, in the order the range walk below visits them.  One aligned 128-byte
 // record = ONE memory round trip per beam instead of the dependent chain cell_start ->
-// ranges -> records.  Unused slots hold x = +inf (squared distance +inf, never the nearest);
+// ranges -> records.  Unused slots hold x = +inf (squared distance +inf, never the nearest), y = 0, id = -1;
 // n > kNeighCap sends the beam down the range walk.
+// Laid out for the common case (round 3: k_assoc_group's time follows the NUMBER of vector loads a beam issues -- four
+// instead of six: -13 % -- far more than their bytes or the arithmetic behind them): the first two candidates, both ids
+// and the count are three 16-byte loads out of the first 48 bytes; a neighbourhood holds one or two landmarks in
+// 93 % of the cells of S2's map, three in 5 %, four in 1 %.
+#ifndef ICM_NEIGH_FAST
+#define ICM_NEIGH_FAST 2
+#endif
 constexpr int kNeighCap = 4;
+constexpr int kNeighFast = ICM_NEIGH_FAST;   // candidates every beam reads (2 or 3); the rest of a record only where a neighbourhood has more
 struct __attribute__((aligned(128))) NeighRec {
-    double x[kNeighCap];
-    double y[kNeighCap];
-    int id[kNeighCap];
-    int n;
+    double x0, y0;         //  0
+    double x1, y1;         // 16
+    int id0, id1, n, id2;  // 32
+    double x2, y2;         // 48
+    double x3, y3;         // 64
+    int id3;               // 80
     int pad[11];
 };
 static_assert(sizeof(NeighRec) == 128, "NeighRec is one 128-byte line");
@@ -448,26 +458,66 @@ __device__ __forceinline__ int assoc_grid(const GridView& g, const GridParams& g
     // 32-bit lane offset instead of 64-bit address arithmetic per beam)
     const unsigned off = ((unsigned)cy * (unsigned)gp.nx + (unsigned)cx) << 7;
     const char* __restrict__ r = reinterpret_cast<const char*>(g.nb) + off;
-    const double4 xa = *reinterpret_cast<const double4*>(r), ya = *reinterpret_cast<const double4*>(r + 32);
-    const int4 ia = *reinterpret_cast<const int4*>(r + 64);
-    const int n = *reinterpret_cast<const int*>(r + 80);
-    // squared distances to the (at most four) candidates; empty slots hold x = +inf
-    double dx = xa.x - wx, dy = ya.x - wy;
+    // the part of the record every beam reads: candidates 0 .. kNeighFast-1, the ids 0..2 and the count
+    const double2 p0 = *reinterpret_cast<const double2*>(r), p1 = *reinterpret_cast<const double2*>(r + 16);
+    const int4 ic = *reinterpret_cast<const int4*>(r + 32);   // id0, id1, n, id2
+    double2 p2 = {__builtin_huge_val(), 0.0};
+    if (kNeighFast >= 3) p2 = *reinterpret_cast<const double2*>(r + 48);
+    const int n = ic.z;
+    // squared distances to the candidates; empty slots hold x = +inf
+    double dx = p0.x - wx, dy = p0.y - wy;
     const double s0 = dx * dx + dy * dy;
-    dx = xa.y - wx; dy = ya.y - wy;
+    dx = p1.x - wx; dy = p1.y - wy;
     const double s1 = dx * dx + dy * dy;
-    dx = xa.z - wx; dy = ya.z - wy;
-    const double s2 = dx * dx + dy * dy;
-    dx = xa.w - wx; dy = ya.w - wy;
-    const double s3 = dx * dx + dy * dy;
+    dx = p2.x - wx; dy = p2.y - wy;
+    double s2 = dx * dx + dy * dy;   // (kNeighFast == 2: what an empty slot gives, for the lanes that do not read theirs below)
+    double s3 = s2;
+    int id2 = kNeighFast >= 3 ? ic.w : -1, id3 = -1;
+    // The rest of the record, for the lanes whose neighbourhood holds more candidates than that -- and only when the wave
+    // has such a lane at all.  A lane that does not read its slots 2 / 3 uses what an empty slot holds (x = +inf, y = 0,
+    // id = -1: its record's slots ARE empty), so every lane decides on exactly the four values the whole record gives.
+    const bool more = n > kNeighFast;
+    bool four = kNeighFast >= 3;   // s2 / s3 enter the decision below (always, when slot 2 is read by everybody)
+    if (__builtin_expect(__ballot(more) != 0ull, 0)) {
+        four = true;
+        if (kNeighFast >= 3) {   // empty slot 3 of the lanes that stay out
+            dx = __builtin_huge_val() - wx; dy = 0.0 - wy;
+            s3 = dx * dx + dy * dy;
+        }
+        if (more) {
+            if (kNeighFast < 3) {
+                const double2 q2 = *reinterpret_cast<const double2*>(r + 48);
+                dx = q2.x - wx; dy = q2.y - wy;
+                s2 = dx * dx + dy * dy;
+                id2 = ic.w;
+            }
+            const double2 q3 = *reinterpret_cast<const double2*>(r + 64);
+            id3 = *reinterpret_cast<const int*>(r + 80);
+            dx = q3.x - wx; dy = q3.y - wy;
+            s3 = dx * dx + dy * dy;
+        }
+    } else if (kNeighFast >= 3) {
+        dx = __builtin_huge_val() - wx; dy = 0.0 - wy;   // (slot 3 of a record with at most three candidates)
+        s3 = dx * dx + dy * dy;
+    }
     // the nearest one and whether a second candidate is within a relative 1e-15 of it (then the reference's
     // rule on the rounded sqrt decides: the range walk).  With no near tie exactly one c_i is set.
-    // (No early exit on an empty neighbourhood: every load of the record is in flight before anything is decided.)
-    const double best = fmin(fmin(s0, s1), fmin(s2, s3));
-    const double lim = best * (1.0 + 1e-15);
-    const bool c0 = s0 <= lim, c1 = s1 <= lim, c2 = s2 <= lim, c3 = s3 <= lim;
+    // Two-slot form (no lane of the wave has a third candidate): what the four-slot form below gives when slots 2 and 3
+    // are empty -- fmin skips a NaN, an infinite s2 is "within the limit" only when every candidate's distance is infinite
+    // too, and then slot 0 or 1 is picked first either way.
+    double best, lim;
+    bool c0, c1, c2 = false, c3 = false;
+    if (four) {
+        best = fmin(fmin(s0, s1), fmin(s2, s3));
+        lim = best * (1.0 + 1e-15);
+        c0 = s0 <= lim; c1 = s1 <= lim; c2 = s2 <= lim; c3 = s3 <= lim;
+    } else {
+        best = fmin(s0, s1);
+        lim = best * (1.0 + 1e-15);
+        c0 = s0 <= lim; c1 = s1 <= lim;
+    }
     const bool tie = (c0 & (c1 | c2 | c3)) | (c1 & (c2 | c3)) | (c2 & c3);
-    const int bid = c0 ? ia.x : (c1 ? ia.y : (c2 ? ia.z : ia.w));
+    const int bid = c0 ? ic.x : (c1 ? ic.y : (c2 ? id2 : id3));
     int lab = ((c0 | c1 | c2 | c3) & (bid >= 0) & !(best > thr2)) ? bid : -1;   // (no c_i: a non-finite point)
     if (__builtin_expect((n > kNeighCap) | ((n != 0) & tie), 0)) lab = assoc_grid_walk(g, gp, cx, cy, wx, wy, thr, thr2);
     return n == 0 ? -1 : lab;
@@ -488,28 +538,32 @@ __global__ __launch_bounds__(kBlock) void k_neigh_table(GridView g, NeighRec* __
     const int pb = g.cell_start[cy * gp.nx + c0], nb = cy != r0 ? g.cell_start[cy * gp.nx + c1 + 1] - pb : 0;
     const int pc = g.cell_start[r2 * gp.nx + c0], nc = r2 != cy ? g.cell_start[r2 * gp.nx + c1 + 1] - pc : 0;
     const int n = na + nb + nc;
-    NeighRec rec;
+    double x[kNeighCap], y[kNeighCap];
+    int id[kNeighCap];
+#pragma unroll
     for (int i = 0; i < kNeighCap; ++i) {
-        rec.x[i] = __builtin_huge_val();
-        rec.y[i] = 0.0;
-        rec.id[i] = -1;
+        x[i] = __builtin_huge_val();
+        y[i] = 0.0;
+        id[i] = -1;
     }
-    for (int i = 0; i < kNeighCap; ++i) {  // (a fixed-trip loop: rec stays in registers)
+#pragma unroll
+    for (int i = 0; i < kNeighCap; ++i) {  // (a fixed-trip loop: the record stays in registers)
         if (i < n) {
             const int p = i < na ? pa + i : (i < na + nb ? pb + (i - na) : pc + (i - na - nb));
             const LmRec q = g.lm[p];
-            rec.x[i] = q.x;
-            rec.y[i] = q.y;
-            rec.id[i] = q.id;
+            x[i] = q.x;
+            y[i] = q.y;
+            id[i] = q.id;
         }
     }
-    rec.n = n;
-    double4* o = reinterpret_cast<double4*>(out + c);
-    o[0] = make_double4(rec.x[0], rec.x[1], rec.x[2], rec.x[3]);
-    o[1] = make_double4(rec.y[0], rec.y[1], rec.y[2], rec.y[3]);
-    int4* oi = reinterpret_cast<int4*>(out[c].id);
-    oi[0] = make_int4(rec.id[0], rec.id[1], rec.id[2], rec.id[3]);
-    out[c].n = n;
+    double4* o = reinterpret_cast<double4*>(out + c);   // (the NeighRec layout, in 32-byte stores)
+    o[0] = make_double4(x[0], y[0], x[1], y[1]);
+    int4* oi = reinterpret_cast<int4*>(&out[c].id0);
+    oi[0] = make_int4(id[0], id[1], n, id[2]);
+    double2* o2 = reinterpret_cast<double2*>(&out[c].x2);
+    o2[0] = make_double2(x[2], y[2]);
+    o2[1] = make_double2(x[3], y[3]);
+    out[c].id3 = id[3];
 }
 
 // Brute-force form of the same association (all K landmarks, table tiled through LDS): the
@@ -2306,14 +2360,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_moments_h(const double* __restr
                                                            const double* __restrict__ off_x, const double* __restrict__ off_y,
                                                            const double* __restrict__ off_n, double* __restrict__ pose_m,
                                                            double2* __restrict__ tgt_out, int tl_begin = 0, int tl_end = -1,
-                                                           const double* __restrict__ rot = nullptr,
-                                                           double* __restrict__ zero_out = nullptr, size_t zero_n = 0) {
-    // (zero_out: the [superchunk x L] matrix, whose last reader -- k_rec_push -- is the launch in front of this one: cleared
-    // here for the next sweep, a store per thread, instead of by a memset launch behind an event of its own)
-    if (zero_out) {
-        const size_t nthr = (size_t)gridDim.x * kBlock;
-        for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < zero_n; q += nthr) zero_out[q] = 0.0;
-    }
+                                                           const double* __restrict__ rot = nullptr) {
     const int sub = threadIdx.x & 15;
     const int tl = tl_begin + ((blockIdx.x * kBlock + threadIdx.x) >> 4);   // poses [tl_begin, tl_end)
     const bool live = tl < (tl_end < 0 ? nloc : tl_end);
@@ -2623,10 +2670,16 @@ __device__ unsigned long long g_wave_ts[4 * 16384];
 #endif
 template <bool QUAD, bool FOLD>
 __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags,
-                                                          int spin_limit, int* __restrict__ deferred) {
+                                                          int spin_limit, int* __restrict__ deferred,
+                                                          double* __restrict__ zero_out = nullptr, unsigned zero_n = 0) {
     const int lane = lane_id();
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (gw >= 2 * nw) return;
+    // zero_out: phase B's [superchunk x L] matrix, whose last reader ran before this launch: the even waves clear it for
+    // the next sweep before they start to wait for their odd neighbours -- a few dozen stores per lane into a memory
+    // system this launch leaves idle, instead of a memset launch (or 15 MB more for one of phase B's bandwidth-bound kernels)
+    if (zero_out && gw >= nw)
+        for (unsigned q = (unsigned)(gw - nw) * kWave + lane; q < zero_n; q += (unsigned)nw * kWave) zero_out[q] = 0.0;
     if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;   // (the flags were final before this launch began: uniform over the grid)
     const int epoch = a.epoch;
     const bool even = gw >= nw;
