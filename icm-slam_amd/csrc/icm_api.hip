@@ -79,6 +79,7 @@ struct icm_handle {
     DevBuf<double> pose_cs;   // (T,2): (cos, sin)(theta) of every pose as it stands (valid with rot_valid)
     DevBuf<int> nkept, boff, bk;
     DevBuf<double> bd, bx, by, pose_s2;
+    DevBuf<double2> bxy, gh_bxy;   // the kept beams' body points once more, interleaved (k_assoc_group: one load per beam)
     std::vector<int> h_boff;
     int64_t nnz = 0;
 
@@ -380,7 +381,7 @@ int icm_destroy(icm_handle* h) {
     DevBuf<int>* di[] = {&h->nkept, &h->boff, &h->bk, &h->g_cell, &h->label, &h->bloc, &h->st_label,
                          &h->nent, &h->isnew, &h->ent_off, &h->new_rank, &h->e_val, &h->e_k, &h->sval, &h->lm_off, &h->flags, &h->scan_tot};
     for (auto* b : di) b->release();
-    h->g_lm.release(); h->gpar.release(); h->g_nb.release(); h->st_k.release();
+    h->g_lm.release(); h->gpar.release(); h->g_nb.release(); h->st_k.release(); h->bxy.release();
     h->fl_nn.release(); h->fl_lab.release(); h->fl_comp.release(); h->fl_csize.release(); h->fl_isl.release(); h->fl_rank.release();
     h->fl_scan_tot.release(); h->fl_state.release(); h->fl_nd.release();
     h->fl_cid.release(); h->fl_cell_cnt.release(); h->fl_cell_fill.release(); h->fl_info.release();
@@ -390,7 +391,7 @@ int icm_destroy(icm_handle* h) {
     h->skey.release();
     h->sort_tmp.release();
     h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release(); h->solve_counts.release(); h->need.release(); h->odo_cs.release(); h->pose_cs.release();
-    h->gh_ranges.release(); h->gh_bd.release(); h->gh_bx.release(); h->gh_by.release(); h->gh_s2.release(); h->gh_sx.release(); h->gh_sy.release();
+    h->gh_ranges.release(); h->gh_bd.release(); h->gh_bx.release(); h->gh_by.release(); h->gh_bxy.release(); h->gh_s2.release(); h->gh_sx.release(); h->gh_sy.release();
     h->gh_rot.release(); h->gh_m.release(); h->gh_nkept.release(); h->gh_boff.release(); h->gh_bk.release(); h->gh_label.release(); h->gh_bloc.release();
     h->gh_st_label.release(); h->gh_misc.release(); h->gh_st_k.release();
     if (h->ev_gh0) (void)hipEventDestroy(h->ev_gh0);
@@ -536,11 +537,12 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->bd.reserve(nz));
     HIPCHK(h, h->bx.reserve(nz));
     HIPCHK(h, h->by.reserve(nz));
+    HIPCHK(h, h->bxy.reserve(nz));
     HIPCHK(h, h->pose_s2.reserve(3 * (size_t)nloc));
     HIPCHK(h, h->pose_c.reserve(3 * (size_t)nloc));
     HIPCHK(h, h->pose_m.reserve(17 * (size_t)nloc));
     HIPCHK(h, h->rot.reserve(2 * (size_t)nloc));
-    TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p)));
+    TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p, h->bxy.p)));
     // per-sweep buffers sized by the kept beams
     // staged entries (packed area, sparse area behind it) and the per-entry prefixes that live at the same places
     if (!staging_layout(h->nnz, nloc, h->stl)) FAIL(h, ICM_ERR_CAPACITY, "too many kept beams for 32-bit entry offsets");
@@ -596,7 +598,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         // a one-pose k_assoc_group with an all-zero reservation plan stages them at sparse0 = kWave
         const size_t Bz = (size_t)B, gst = (size_t)kWave + Bz + 512;
         HIPCHK(h, h->gh_nkept.reserve(2)); HIPCHK(h, h->gh_boff.reserve(2)); HIPCHK(h, h->gh_bk.reserve(Bz));
-        HIPCHK(h, h->gh_bd.reserve(Bz)); HIPCHK(h, h->gh_bx.reserve(Bz)); HIPCHK(h, h->gh_by.reserve(Bz)); HIPCHK(h, h->gh_s2.reserve(3));
+        HIPCHK(h, h->gh_bd.reserve(Bz)); HIPCHK(h, h->gh_bx.reserve(Bz)); HIPCHK(h, h->gh_by.reserve(Bz)); HIPCHK(h, h->gh_bxy.reserve(Bz)); HIPCHK(h, h->gh_s2.reserve(3));
         HIPCHK(h, h->gh_label.reserve(Bz)); HIPCHK(h, h->gh_bloc.reserve(Bz));
         HIPCHK(h, h->gh_st_label.reserve(gst)); HIPCHK(h, h->gh_st_k.reserve(gst)); HIPCHK(h, h->gh_sx.reserve(gst)); HIPCHK(h, h->gh_sy.reserve(gst));
         HIPCHK(h, h->gh_misc.reserve(32)); HIPCHK(h, h->gh_rot.reserve(2)); HIPCHK(h, h->gh_m.reserve(17));
@@ -604,7 +606,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         HIPCHK(h, hipMemsetAsync(h->gh_m.p, 0, 17 * sizeof(double), h->stream));
         k_prefilter<false><<<1, kBlock, lds, h->stream>>>(h->gh_ranges.p, h->cosb.p, h->sinb.p, 1, B, h->cfg.rango_laser_max, h->cfg.dist_thr, h->gh_nkept.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->gh_nkept.p, h->gh_boff.p, 1);
-        k_prefilter<true><<<1, kBlock, lds, h->stream>>>(h->gh_ranges.p, h->cosb.p, h->sinb.p, 1, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->gh_boff.p, h->gh_bk.p, h->gh_bd.p, h->gh_bx.p, h->gh_by.p, h->gh_s2.p);
+        k_prefilter<true><<<1, kBlock, lds, h->stream>>>(h->gh_ranges.p, h->cosb.p, h->sinb.p, 1, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->gh_boff.p, h->gh_bk.p, h->gh_bd.p, h->gh_bx.p, h->gh_by.p, h->gh_s2.p, h->gh_bxy.p);
         int gb[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(gb, h->gh_boff.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -926,7 +928,7 @@ int icm_sweep_local(icm_handle* h) {
     // Production form (no pre-set labels, no per-beam dump): PERSISTENT waves, as many workgroups as the chip holds at
     // once (assoc_wg_per_cu per CU: 8 with the 128-slot table, half of that with the 256-slot one), each wave striding
     // over the poses with the next pose's header and first beams in flight.  assoc_wg_per_cu == 0: one pose per wave.
-#define ASSOC_ARGS h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bx.p, h->by.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
+#define ASSOC_ARGS h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bxy.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
         h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->fl, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->stl.sparse0
 #define ASSOC_GROUP(PRE, DBG, HS)                                                                                  \
     do {                                                                                                           \
@@ -1079,7 +1081,7 @@ static int launch_ghost(icm_handle* h) {
     }
     int* gm = h->gh_misc.p;   // [0] nent [1] isnew [2] st_off [3..4] reservation plan (zeros) [8..23] the ghost launch's flags
     HIPCHK(h, hipMemsetAsync(gm + 8, 0, 16 * sizeof(int), gs));
-    k_assoc_group<false, false, 256><<<1, kBlock, 0, gs>>>(h->x, h->x0.p, (int)h->t_begin - 1, 1, h->gh_boff.p, h->gh_bx.p, h->gh_by.p,
+    k_assoc_group<false, false, 256><<<1, kBlock, 0, gs>>>(h->x, h->x0.p, (int)h->t_begin - 1, 1, h->gh_boff.p, h->gh_bxy.p,
         GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p}, h->cfg.dist_thr, h->thr2, h->gh_label.p, h->gh_bloc.p, h->gh_st_label.p,
         h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p, gm, gm + 1, gm + 8, h->gh_rot.p, h->ghost_n, gm + 2, gm + 3, 0, kWave);
     k_ghost_moments<<<1, kWave, 0, gs>>>(h->x, (int)h->t_begin - 1, gm, gm + 2, h->gh_st_label.p, h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p,

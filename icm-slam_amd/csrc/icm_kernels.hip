@@ -210,7 +210,8 @@ __global__ __launch_bounds__(kBlock) void k_prefilter(const double* __restrict__
                                                       double rmax, double thr, int* __restrict__ nkept,
                                                       const int* __restrict__ boff, int* __restrict__ bk,
                                                       double* __restrict__ bd, double* __restrict__ bx,
-                                                      double* __restrict__ by, double* __restrict__ pose_s2) {
+                                                      double* __restrict__ by, double* __restrict__ pose_s2,
+                                                      double2* __restrict__ bxy = nullptr) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int w = wave_in_block(), lane = lane_id();
     const int t = blockIdx.x * kWavesPerBlock + w;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kBlock) void k_prefilter(const double* __restrict__
             bd[p] = lm[i];
             bx[p] = lpx[i];
             by[p] = lpy[i];
+            if (bxy) bxy[p] = make_double2(lpx[i], lpy[i]);   // (phase A's copy: one 16-byte load per beam, see k_assoc_group)
             sxx += lpx[i] * lpx[i];
             sxy += lpx[i] * lpy[i];
             syy += lpy[i] * lpy[i];
@@ -754,7 +756,7 @@ template <bool PRELABEL, bool DEBUG, int HS, int PPW = 1, int WPB = kWavesPerBlo
 __global__ __launch_bounds__(WPB * kWave) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_ASSOC_WPE : 4, HS == 128 ? 8 : 5)))
 void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int t_begin, int nloc, const int* __restrict__ boff,
-                                                        const double* __restrict__ bx, const double* __restrict__ by,
+                                                        const double2* __restrict__ bxy,
                                                         GridView g, double thr, double thr2, int* __restrict__ label,
                                                         int* __restrict__ bloc, int* __restrict__ st_label,
                                                         unsigned short* __restrict__ st_k, double* __restrict__ st_sbx,
@@ -782,8 +784,10 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     PoseTable<HS>& T = tables[wave_in_block()];
     const GridParams gp = *g.par;
     // (explicit 32-bit byte offsets from a scalar base: a pose has far fewer than 2^29 beams)
-    auto beam_at = [](const double* __restrict__ base, unsigned idx) {
-        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
+    // (a beam's body-frame point is ONE 16-byte load from the interleaved copy the pre-filter leaves beside its two
+    // arrays: this kernel's time follows the number of vector loads it issues)
+    auto beam_at = [](const double2* __restrict__ base, unsigned idx) {
+        return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + (idx << 4));
     };
     // header and first 64 beams of the pose that comes next (at first: of the wave's first pose)
     int hj0 = __builtin_amdgcn_readfirstlane(boff[w0]), hj1 = __builtin_amdgcn_readfirstlane(boff[w0 + 1]);
@@ -798,8 +802,9 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     double fbx = 0.0, fby = 0.0;
     if (hj1 > hj0) {
         const unsigned i0 = min((unsigned)lane, (unsigned)(hj1 - hj0) - 1u);
-        fbx = beam_at(bx + hj0, i0);
-        fby = beam_at(by + hj0, i0);
+        const double2 f = beam_at(bxy + hj0, i0);
+        fbx = f.x;
+        fby = f.y;
     }
     int nj0 = 0, nj1 = 0;   // persistent: beam range of the pose after next (scalar loads, two poses ahead)
     if (PERSIST && w0 + stride < nloc) {
@@ -830,8 +835,9 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
             hst = rot[2 * (size_t)tn + 1];
             const unsigned i1 = min((unsigned)lane, (unsigned)max(hj1 - hj0, 1) - 1u);   // (a pose without beams reads one in-range beam nobody uses)
             const unsigned b1 = (unsigned)min(hj0, max(nnz_total - 1, 0));
-            fbx = beam_at(bx + b1, i1);
-            fby = beam_at(by + b1, i1);
+            const double2 f = beam_at(bxy + b1, i1);
+            fbx = f.x;
+            fby = f.y;
         }
     } else if (PPW > 1 && pp + 1 < PPW && tl + 1 < nloc) {   // the next pose's header and first beams, requested now
         hj0 = j1;
@@ -840,8 +846,9 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         hct = rot[2 * (size_t)(tl + 1)];
         hst = rot[2 * (size_t)(tl + 1) + 1];
         const unsigned i1 = min((unsigned)lane, (unsigned)(nnz_total - j1) - 1u);   // (clamped to the shard's last beam)
-        fbx = beam_at(bx + j1, i1);
-        fby = beam_at(by + j1, i1);
+        const double2 f = beam_at(bxy + j1, i1);
+        fbx = f.x;
+        fby = f.y;
     }
     if (j0 == j1) {
         if (lane == 0) {
@@ -853,8 +860,7 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     }
     // this pose's reserved place (scalar loads, in flight while the beams are grouped)
     const int plan0 = __builtin_amdgcn_readfirstlane(plan[tl]), plan1 = __builtin_amdgcn_readfirstlane(plan[tl + 1]);
-    const double* __restrict__ bxp = bx + j0;
-    const double* __restrict__ byp = by + j0;
+    const double2* __restrict__ bxyp = bxy + j0;
     const unsigned nbeam = (unsigned)(j1 - j0);
     for (int s = lane; s < kHash; s += kWave) {
         T.key[s] = kEmpty;
@@ -876,8 +882,9 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         const double bxx = nbx, byy = nby;   // (lanes beyond the pose's last beam hold a copy of it: never a head or a tail, read by nobody)
         {
             const unsigned on = min((unsigned)(j - j0) + (unsigned)kWave, nbeam - 1u);
-            nbx = beam_at(bxp, on);
-            nby = beam_at(byp, on);
+            const double2 nb = beam_at(bxyp, on);
+            nbx = nb.x;
+            nby = nb.y;
         }
         if (valid) {
             if (PRELABEL) {
