@@ -49,7 +49,7 @@ def classify(ins):
 
 
 def main():
-    prefix = sys.argv[1] if len(sys.argv) > 1 else "_ZN3icm13k_assoc_groupILb0ELb0ELi128ELi1EEE"
+    prefix = sys.argv[1] if len(sys.argv) > 1 else "_ZN3icm13k_assoc_groupILb0ELb0ELi128ELi1ELi4EEE"
     cur, blocks = "entry", collections.OrderedDict({"entry": []})
     for l in kernel_lines(prefix):
         m = re.match(r"^(\.LBB\d+_\d+):", l)
