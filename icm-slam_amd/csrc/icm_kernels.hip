@@ -2683,11 +2683,15 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (gw >= 2 * nw) return;
     // zero_out: phase B's [superchunk x L] matrix, whose last reader ran before this launch: the even waves clear it for
-    // the next sweep before they start to wait for their odd neighbours -- a few dozen stores per lane into a memory
-    // system this launch leaves idle, instead of a memset launch (or 15 MB more for one of phase B's bandwidth-bound kernels)
-    if (zero_out && gw >= nw)
-        for (unsigned q = (unsigned)(gw - nw) * kWave + lane; q < zero_n; q += (unsigned)nw * kWave) zero_out[q] = 0.0;
-    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;   // (the flags were final before this launch began: uniform over the grid)
+    // the next sweep WHILE they wait for their odd neighbours, one store per lane and poll -- a few dozen stores per lane
+    // into a memory system this launch leaves idle, instead of a memset launch (or 15 MB more for one of phase B's
+    // bandwidth-bound kernels).  (Not all at once at the head of the launch: 15 MB of stores in front of the odd waves'
+    // first loads delayed the whole chain by 4-5 us.)
+    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) {   // (the flags were final before this launch began: uniform over the grid)
+        if (zero_out && gw >= nw)   // (the matrix is cleared whatever becomes of the sweep: the host counts on it)
+            for (unsigned q = (unsigned)(gw - nw) * kWave + lane; q < zero_n; q += (unsigned)nw * kWave) zero_out[q] = 0.0;
+        return;
+    }
     const int epoch = a.epoch;
     const bool even = gw >= nw;
     const int wv = even ? gw - nw : gw;
@@ -2703,23 +2707,34 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
     if (mine) load_pose_in(a, tg, in);
     if (even) {
         int ready = 1;
-        if (lane == 0) {
-            for (int d = 0; d < 2 && ready; ++d) {   // the (at most) two odd waves that hold this wave's neighbours
-                const int ow = wv + d - g.shift;
-                if (ow < 0 || ow >= nw) continue;
-                int spins = 0;
-                while (__hip_atomic_load(&flags[ow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                    if (++spins > spin_limit) {
-                        ready = 0;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(8);
+        unsigned zq = (unsigned)wv * kWave + lane;   // this lane's next word of zero_out
+        const unsigned zstride = (unsigned)nw * kWave;
+        for (int d = 0; d < 2 && ready; ++d) {   // the (at most) two odd waves that hold this wave's neighbours
+            const int ow = wv + d - g.shift;     // (wave-uniform loop: lane 0 polls, every lane clears)
+            if (ow < 0 || ow >= nw) continue;
+            int spins = 0;
+            for (;;) {
+                int f = 0;
+                if (lane == 0) f = __hip_atomic_load(&flags[ow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f = __builtin_amdgcn_readfirstlane(f);
+                if (f == epoch) break;
+                if (++spins > spin_limit) {
+                    ready = 0;
+                    break;
                 }
+                if (zero_out && zq < zero_n) {
+                    zero_out[zq] = 0.0;
+                    zq += zstride;
+                }
+                __builtin_amdgcn_s_sleep(8);
             }
-            if (!ready) deferred[wv] = 1;   // (read by the next launch: a kernel boundary, no fence needed)
         }
-        ready = __builtin_amdgcn_readfirstlane(ready);
-        if (!ready) return;                 // wave-uniform: x is left untouched
+        if (zero_out)
+            for (; zq < zero_n; zq += zstride) zero_out[zq] = 0.0;   // (what the wait left over)
+        if (!ready) {
+            if (lane == 0) deferred[wv] = 1;   // (read by the next launch: a kernel boundary, no fence needed)
+            return;                             // wave-uniform: x is left untouched
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
