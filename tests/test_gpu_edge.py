@@ -122,6 +122,46 @@ def test_brute_force_equals_grid_at_s1_size():
     assert (out[0][0] >= 0).all()
 
 
+def test_crowded_neighbourhoods_take_the_rest_of_the_record_and_the_walk():
+    """The cell records of the grid search hold the first two candidates where every beam reads them and the other two
+    where only the lanes that need them do (and more than four send the beam down the range walk): a reference map with
+    decoys 0.25 .. 0.9 m around every landmark -- neighbourhoods of 1 .. 12 candidates, exact mirror images for ties --
+    must give the labels of the literal all-landmarks search, beam for beam."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    wl = make_workload(1350, 400, 360)   # (one lane through a 50 m field, ends inside it)
+    rng = np.random.default_rng(5)
+    m0 = wl.map_init
+    parts = [m0]
+    for k, r in enumerate((0.25, 0.45, 0.7, 0.9)):
+        ang = rng.uniform(0, 2 * np.pi, m0.shape[1])
+        keep = rng.random(m0.shape[1]) < (0.7, 0.5, 0.4, 0.3)[k]
+        d = r * np.stack((np.cos(ang), np.sin(ang)))
+        parts.append((m0 + d)[:, keep])
+        if k == 1:   # mirror images: two candidates at exactly the same distance from points on the landmark's bearing
+            parts.append((m0 - d)[:, keep])
+    m = np.ascontiguousarray(np.concatenate(parts, axis=1))
+    assert m.shape[1] > 3 * m0.shape[1]
+    cfgd = dict(wl.config)
+    cfgd["L"] = m.shape[1] + 4096
+    eng = SweepEngine(ConfigICM(D=cfgd))
+    eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+    eng.set_debug(True)
+    out = []
+    for brute in (False, True):
+        eng.set_brute_force(brute)
+        eng.set_state(m, wl.x_init, wl.x0)
+        eng.sweep_device("redblack")
+        out.append((eng.association()[0].copy(),) + eng.get_state())
+    eng.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert np.array_equal(a, b)
+    # the decoys are really in play: a share of the beams goes to them (10 % here)
+    assert (out[0][0] >= m0.shape[1]).mean() > 0.05
+
+
 def test_s2_full_size_properties():
     """BASELINE configs[3] at full size (100k poses / 10k landmarks / 720 beams): the sweep is
     deterministic (two runs bit-equal), the sharded phase path equals the unsharded one, every
