@@ -79,6 +79,7 @@ struct icm_handle {
     DevBuf<double> pose_cs;   // (T,2): (cos, sin)(theta) of every pose as it stands (valid with rot_valid)
     DevBuf<int> nkept, boff, bk;
     DevBuf<double> bd, bx, by, pose_s2;
+    DevBuf<unsigned long long> kmask, gh_kmask;   // the pre-filter's decisions: one bit per in-range beam (pass 1 -> pass 2)
     DevBuf<double2> bxy, gh_bxy;   // the kept beams' body points once more, interleaved (k_assoc_group: one load per beam)
     std::vector<int> h_boff;
     int64_t nnz = 0;
@@ -391,7 +392,7 @@ int icm_destroy(icm_handle* h) {
     h->skey.release();
     h->sort_tmp.release();
     h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release(); h->solve_counts.release(); h->need.release(); h->odo_cs.release(); h->pose_cs.release();
-    h->gh_ranges.release(); h->gh_bd.release(); h->gh_bx.release(); h->gh_by.release(); h->gh_bxy.release(); h->gh_s2.release(); h->gh_sx.release(); h->gh_sy.release();
+    h->gh_ranges.release(); h->gh_bd.release(); h->gh_bx.release(); h->gh_by.release(); h->gh_bxy.release(); h->gh_kmask.release(); h->kmask.release(); h->gh_s2.release(); h->gh_sx.release(); h->gh_sy.release();
     h->gh_rot.release(); h->gh_m.release(); h->gh_nkept.release(); h->gh_boff.release(); h->gh_bk.release(); h->gh_label.release(); h->gh_bloc.release();
     h->gh_st_label.release(); h->gh_misc.release(); h->gh_st_k.release();
     if (h->ev_gh0) (void)hipEventDestroy(h->ev_gh0);
@@ -526,7 +527,8 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prefilter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prefilter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nb = nblocks_waves(nloc);
-    TIMED(h, KID_PREFILTER, (k_prefilter<false><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, h->nkept.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)));
+    HIPCHK(h, h->kmask.reserve((size_t)nloc * (size_t)((B + kWave - 1) / kWave)));
+    TIMED(h, KID_PREFILTER, (k_prefilter<false><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, h->nkept.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->thr2, h->kmask.p)));
     k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->nkept.p, h->boff.p, nloc);
     h->h_boff.assign((size_t)nloc + 1, 0);
     HIPCHK(h, hipMemcpyAsync(h->h_boff.data(), h->boff.p, ((size_t)nloc + 1) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -542,7 +544,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->pose_c.reserve(3 * (size_t)nloc));
     HIPCHK(h, h->pose_m.reserve(17 * (size_t)nloc));
     HIPCHK(h, h->rot.reserve(2 * (size_t)nloc));
-    TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p, h->bxy.p)));
+    TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p, h->bxy.p, h->thr2, h->kmask.p)));
     // per-sweep buffers sized by the kept beams
     // staged entries (packed area, sparse area behind it) and the per-entry prefixes that live at the same places
     if (!staging_layout(h->nnz, nloc, h->stl)) FAIL(h, ICM_ERR_CAPACITY, "too many kept beams for 32-bit entry offsets");
@@ -598,15 +600,15 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         // a one-pose k_assoc_group with an all-zero reservation plan stages them at sparse0 = kWave
         const size_t Bz = (size_t)B, gst = (size_t)kWave + Bz + 512;
         HIPCHK(h, h->gh_nkept.reserve(2)); HIPCHK(h, h->gh_boff.reserve(2)); HIPCHK(h, h->gh_bk.reserve(Bz));
-        HIPCHK(h, h->gh_bd.reserve(Bz)); HIPCHK(h, h->gh_bx.reserve(Bz)); HIPCHK(h, h->gh_by.reserve(Bz)); HIPCHK(h, h->gh_bxy.reserve(Bz)); HIPCHK(h, h->gh_s2.reserve(3));
+        HIPCHK(h, h->gh_bd.reserve(Bz)); HIPCHK(h, h->gh_bx.reserve(Bz)); HIPCHK(h, h->gh_by.reserve(Bz)); HIPCHK(h, h->gh_bxy.reserve(Bz)); HIPCHK(h, h->gh_kmask.reserve((Bz + kWave - 1) / kWave)); HIPCHK(h, h->gh_s2.reserve(3));
         HIPCHK(h, h->gh_label.reserve(Bz)); HIPCHK(h, h->gh_bloc.reserve(Bz));
         HIPCHK(h, h->gh_st_label.reserve(gst)); HIPCHK(h, h->gh_st_k.reserve(gst)); HIPCHK(h, h->gh_sx.reserve(gst)); HIPCHK(h, h->gh_sy.reserve(gst));
         HIPCHK(h, h->gh_misc.reserve(32)); HIPCHK(h, h->gh_rot.reserve(2)); HIPCHK(h, h->gh_m.reserve(17));
         HIPCHK(h, hipMemsetAsync(h->gh_misc.p, 0, 32 * sizeof(int), h->stream));
         HIPCHK(h, hipMemsetAsync(h->gh_m.p, 0, 17 * sizeof(double), h->stream));
-        k_prefilter<false><<<1, kBlock, lds, h->stream>>>(h->gh_ranges.p, h->cosb.p, h->sinb.p, 1, B, h->cfg.rango_laser_max, h->cfg.dist_thr, h->gh_nkept.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        k_prefilter<false><<<1, kBlock, lds, h->stream>>>(h->gh_ranges.p, h->cosb.p, h->sinb.p, 1, B, h->cfg.rango_laser_max, h->cfg.dist_thr, h->gh_nkept.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->thr2, h->gh_kmask.p);
         k_exscan_i32<<<1, 1024, 0, h->stream>>>(h->gh_nkept.p, h->gh_boff.p, 1);
-        k_prefilter<true><<<1, kBlock, lds, h->stream>>>(h->gh_ranges.p, h->cosb.p, h->sinb.p, 1, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->gh_boff.p, h->gh_bk.p, h->gh_bd.p, h->gh_bx.p, h->gh_by.p, h->gh_s2.p, h->gh_bxy.p);
+        k_prefilter<true><<<1, kBlock, lds, h->stream>>>(h->gh_ranges.p, h->cosb.p, h->sinb.p, 1, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->gh_boff.p, h->gh_bk.p, h->gh_bd.p, h->gh_bx.p, h->gh_by.p, h->gh_s2.p, h->gh_bxy.p, h->thr2, h->gh_kmask.p);
         int gb[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(gb, h->gh_boff.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));

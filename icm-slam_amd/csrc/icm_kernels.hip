@@ -198,10 +198,27 @@ __global__ __launch_bounds__(1024) void k_exscan_i32(const int* __restrict__ in,
     if (tid == 1023) out[n] = part[1023];
 }
 
+// Value of lane `l` (wave-uniform index) in every lane: v_readlane, no LDS round trip.
+__device__ __forceinline__ int lane_bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // ---------------------------------------------------------------------------------------
 // filtrar_z (reference scripts/ICM_SLAM_tools.py:22-58).
-// One wave per scan.  WRITE=false counts the kept beams, WRITE=true stores them at boff[t].
+// One wave per scan.  WRITE=false decides which beams are kept (one 64-bit mask per 64 in-range beams, kmask) and
+// counts them, WRITE=true stores them at boff[t] from the masks.
 // LDS per wave: the in-range beams (index, range, x, y), B entries each.
+// The isolation test `min(100, nearest other in-range beam) <= thr` is an EXISTENCE test: some other beam at a
+// non-zero squared distance s with sqrt(s) <= thr, i.e. s <= thr2 (the largest double whose rounded sqrt is <= thr:
+// the association's gate) -- or thr >= 100.  No minimum, no square root, any order.  Round 3: the beams next to a beam
+// in the list (next in bearing) are tried first, sixteen of them, which settles nearly every beam that stays; the few
+// left over -- the isolated ones, which need every other beam to be ruled out -- are then taken one at a time with the
+// other beams spread over the wave's lanes (64 candidates per step instead of one).  ~1500 -> ~430 steps of the pair
+// test per scan, and the second pass repeats none of it: 5.9 -> 1.x ms per 100 000 scans of 720 beams.
 // ---------------------------------------------------------------------------------------
 template <bool WRITE>
 __global__ __launch_bounds__(kBlock) void k_prefilter(const double* __restrict__ ranges,
@@ -211,7 +228,8 @@ __global__ __launch_bounds__(kBlock) void k_prefilter(const double* __restrict__
                                                       const int* __restrict__ boff, int* __restrict__ bk,
                                                       double* __restrict__ bd, double* __restrict__ bx,
                                                       double* __restrict__ by, double* __restrict__ pose_s2,
-                                                      double2* __restrict__ bxy = nullptr) {
+                                                      double2* __restrict__ bxy, double thr2,
+                                                      unsigned long long* __restrict__ kmask) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int w = wave_in_block(), lane = lane_id();
     const int t = blockIdx.x * kWavesPerBlock + w;
@@ -248,24 +266,59 @@ __global__ __launch_bounds__(kBlock) void k_prefilter(const double* __restrict__
         if (WRITE && lane == 0) pose_s2[3 * (size_t)t] = pose_s2[3 * (size_t)t + 1] = pose_s2[3 * (size_t)t + 2] = 0.0;
         return;
     }
-    // isolated-beam rejection: nearest other in-range beam, exact zeros count as 100
+    // isolated-beam rejection
     int kept = 0;
     double sxx = 0.0, sxy = 0.0, syy = 0.0;  // sum of b b^T over the kept beams (pose constant)
+    const int nchunk = (B + kWave - 1) / kWave;
+    const bool all = 100.0 <= thr;           // (the reference caps the distance at 100)
     for (int base = 0; base < cnt; base += kWave) {
         const int i = base + lane;
-        bool keep = false;
-        if (i < cnt) {
-            const double xi = lpx[i], yi = lpy[i];
-            double smin = __builtin_huge_val();
-            for (int j = 0; j < cnt; ++j) {
-                const double dx = xi - lpx[j], dy = yi - lpy[j];
-                const double s = dx * dx + dy * dy;
-                if (s != 0.0 && s < smin) smin = s;
+        unsigned long long mask;
+        if (!WRITE) {
+            const bool live = i < cnt;
+            const double xi = live ? lpx[i] : 0.0, yi = live ? lpy[i] : 0.0;
+            bool found = all;
+            // 1. the beams next to it in the list
+            constexpr int kNear = 8;
+#pragma unroll
+            for (int k = 1; k <= kNear; ++k) {
+                const int ja = i - k, jb = i + k;
+                if (live && ja >= 0) {
+                    const double dx = xi - lpx[ja], dy = yi - lpy[ja];
+                    const double q = dx * dx + dy * dy;
+                    found |= (q != 0.0) & (q <= thr2);
+                }
+                if (live && jb < cnt) {
+                    const double dx = xi - lpx[jb], dy = yi - lpy[jb];
+                    const double q = dx * dx + dy * dy;
+                    found |= (q != 0.0) & (q <= thr2);
+                }
             }
-            const double nn = fmin(100.0, sqrt(smin));
-            keep = nn <= thr;
+            mask = __ballot(live && found);
+            // 2. the beams still without a neighbour, one at a time against all the others, 64 per step
+            unsigned long long open = __ballot(live && !found);
+            while (open != 0ull) {
+                const int l = (int)__builtin_ctzll(open);
+                open &= open - 1ull;
+                const double xl = lane_bcast(xi, l), yl = lane_bcast(yi, l);
+                bool hit = false;
+                for (int jb = 0; jb < cnt && !hit; jb += kWave) {
+                    const int j = jb + lane;
+                    bool h = false;
+                    if (j < cnt) {
+                        const double dx = xl - lpx[j], dy = yl - lpy[j];
+                        const double q = dx * dx + dy * dy;
+                        h = (q != 0.0) & (q <= thr2);
+                    }
+                    hit = __ballot(h) != 0ull;
+                }
+                if (hit) mask |= 1ull << l;
+            }
+            if (lane == 0) kmask[(size_t)t * nchunk + (base >> 6)] = mask;
+        } else {
+            mask = kmask[(size_t)t * nchunk + (base >> 6)];
         }
-        const unsigned long long mask = __ballot(keep);
+        const bool keep = (mask >> lane) & 1ull;
         if (WRITE && keep) {
             const int p = boff[t] + kept + prefix_count(mask, lane);
             bk[p] = lk[i];
@@ -1270,15 +1323,6 @@ __device__ __forceinline__ int table_slot(int* key, int mask, int shift, int lab
         slot = (slot + 1) & mask;
     }
     return slot;
-}
-
-// Value of lane `l` (wave-uniform index) in every lane: v_readlane, no LDS round trip.
-__device__ __forceinline__ int lane_bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ double lane_bcast(double v, int l) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
 // First 64 staged entries of kGroup consecutive poses (lane = entry), requested together.
