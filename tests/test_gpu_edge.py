@@ -122,6 +122,53 @@ def test_brute_force_equals_grid_at_s1_size():
     assert (out[0][0] >= 0).all()
 
 
+def test_prefilter_edge_cases_match_the_oracle():
+    """filtrar_z on hand-made scans against the NumPy oracle (scripts/ICM_SLAM_tools.py:22-58), row for row: nothing in
+    range, one beam in range, isolated beams only, neighbours that sit more than eight places apart in the list of
+    in-range beams (only the all-beams step can find them), exactly coincident points (distance zero counts as 100),
+    runs that end at the 64- and 128-beam boundaries of the kernel's chunks, and a threshold of 100 and more (every
+    in-range beam stays)."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    from oracle import icm_oracle as oc
+    wl = make_workload(300, 49, 360)
+    B, rmax = 360, float(wl.config["rango_laser_max"])
+    rng = np.random.default_rng(11)
+    far = rmax + 1.0
+    scans = []
+    scans.append(np.full(B, far))                                   # nothing in range
+    z = np.full(B, far); z[100:103] = 4.0; scans.append(z)          # median-3 leaves one beam in range
+    z = np.full(B, far); z[10:13] = 3.0; z[200:203] = 3.0; scans.append(z)   # two lone beams, 3+ m apart
+    z = np.full(B, far)                                             # partners 180 degrees apart at 0.3 m: 0.6 m between them,
+    for k in range(0, 170, 9):                                      # with unrelated in-range beams in between in the list
+        z[k:k + 3] = 0.3; z[k + 180:k + 183] = 0.3
+    z[90:93] = 9.0
+    scans.append(z)
+    z = np.full(B, far); z[0:3] = 0.0; z[120:123] = 0.0; z[240:243] = 0.0; scans.append(z)   # coincident points at the origin
+    for n in (63, 64, 65, 127, 128, 129):                           # a wall of n in-range beams
+        z = np.full(B, far); z[5:5 + n] = 5.0 + 0.01 * rng.random(n); scans.append(z)
+    for _ in range(20):                                             # random clutter
+        z = np.where(rng.random(B) < 0.25, rng.uniform(0.2, rmax, B), far); scans.append(z)
+    S = np.ascontiguousarray(np.array(scans))                       # (n, B) pose-major
+    T = S.shape[0]
+    for thr in (float(wl.config["dist_thr"]), 0.05, 100.0, 250.0):
+        cfgd = dict(wl.config); cfgd["dist_thr"] = thr
+        cfg = ConfigICM(D=cfgd)
+        eng = SweepEngine(cfg)
+        eng.upload(S, np.zeros((3, T)), np.zeros((2, T)), pose_major=True)
+        off, bk, d, bx, by = eng.kept_beams()
+        eng.close()
+        ocfg = oc.OracleConfig.from_config(cfg)
+        for t in range(T):
+            rows = oc.filtrar_z(S[t], ocfg)
+            a, b = int(off[t]), int(off[t + 1])
+            assert b - a == len(rows), (thr, t, b - a, len(rows))
+            if len(rows):
+                assert np.array_equal(d[a:b], rows[:, 0]) and np.array_equal(bk[a:b] * np.pi / 180.0, rows[:, 1])
+                assert np.array_equal(bx[a:b], rows[:, 2]) and np.array_equal(by[a:b], rows[:, 3])
+
+
 def test_crowded_neighbourhoods_take_the_rest_of_the_record_and_the_walk():
     """The cell records of the grid search hold the first two candidates where every beam reads them and the other two
     where only the lanes that need them do (and more than four send the beam down the range walk): a reference map with
