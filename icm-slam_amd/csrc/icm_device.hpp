@@ -646,7 +646,7 @@ struct NeverStop {
 };
 template <class F, class S = NeverStop>
 __device__ __forceinline__ bool nelder_mead3(F f, double sx, double sy, double st, double out[6], S stop = S()) {
-    const int maxfun = 600, maxiter = 600;
+    constexpr int maxfun = 600, maxiter = 600;
     const double xatol = 1e-3, fatol = 1e-4;
     const double grow = 1 + 0.05;
     Vtx v0{sx, sy, st, 0.0};
@@ -735,7 +735,10 @@ __device__ __forceinline__ bool nelder_mead3(F f, double sx, double sy, double s
         }
         it += aborted ? 0 : 1;
         stopped = stop();
-        go = !aborted & (nfev < maxfun) & (it < maxiter) & !(settled() | stopped);
+        // (it < maxiter needs no test of its own: every iteration costs at least one evaluation, so nfev >= it + 3, and
+        // the two budgets are the same number)
+        static_assert(maxfun <= maxiter + 3, "the evaluation budget implies the iteration budget");
+        go = !aborted & (nfev < maxfun) & !(settled() | stopped);
     }
     out[0] = v0.x; out[1] = v0.y; out[2] = v0.t; out[3] = v0.f;
     out[4] = (double)it; out[5] = (double)nfev;
