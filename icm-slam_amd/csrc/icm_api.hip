@@ -35,11 +35,11 @@ std::string g_create_err;
 
 enum KernelId {
     KID_PREFILTER = 0, KID_SCAN, KID_ASSOC_BRUTE, KID_ASSOC_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_TOTALS,
-    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_SOLVE_DEFERRED, KID_FILTRAR, KID_NEIGH, KID_CHUNK_L1, KID_CHUNK_L2, KID_LM_L3, KID_REC_PUSH, KID_POSE_ROT, KID_COUNT
+    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_FILTRAR, KID_NEIGH, KID_CHUNK_L1, KID_CHUNK_L2, KID_LM_L3, KID_REC_PUSH, KID_POSE_ROT, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_scan", "k_associate_brute", "k_assoc_group", "k_compact",
                                        "radix_sort_pairs", "k_lm_bounds", "k_lm_scan_totals", "k_stats_prefix",
-                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_solve_deferred", "k_filtrar", "k_neigh_table",
+                                       "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_filtrar", "k_neigh_table",
                                        "k_chunk_l1", "k_chunk_l2", "k_lm_l3", "k_rec_push", "k_pose_rot"};
 
 template <class T>
@@ -136,11 +136,10 @@ struct icm_handle {
         int64_t K = 0, lact = 0;
         bool h_map_valid = true, valid = false, dev_map_current = false;
     } snap;
-    DevBuf<int> solve_flags;  // fused red-black solve: [nw] completion flags of the odd waves | [nw] deferred marks of the even waves
-    DevBuf<unsigned long long> solve_counts;   // over the handle's life: [0] even waves that deferred to the fix-up launch, [1] poses the fix-up solved because a fold-only lane marked them
+    DevBuf<int> solve_flags;  // fused red-black solve: [nw] completion flags of the odd waves | [nw] deferral stamps of the even waves | [2] sync words (waves done, waves deferred)
+    DevBuf<unsigned long long> solve_counts;   // over the handle's life: [0] even waves that deferred, [1] poses solved once more with the complete energy (an evaluation left the folded form's range)
     int solve_flag_waves = 0;
     int solve_epoch = 0;
-    DevBuf<int> need;         // [nloc + 2]: fold-only solves mark the poses they leave to the fix-up (epoch stamped; slot 0 = ghost pose; [nloc + 1] = need_seen)
     int* fl = nullptr;        // this sweep's block of 16 flag / counter words: the sweeps alternate between the two halves of `flags`,
     int fl_parity = 0;        //   and k_lm_l3 clears the other half for the next sweep (no memset launch at a sweep's head)
     bool fl_next_clean = false;
@@ -391,7 +390,7 @@ int icm_destroy(icm_handle* h) {
     h->e_key.release();
     h->skey.release();
     h->sort_tmp.release();
-    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release(); h->solve_counts.release(); h->need.release(); h->odo_cs.release(); h->pose_cs.release();
+    h->rec_label.release(); h->rec_s.release(); h->rec_off.release(); h->ms.release(); h->solve_flags.release(); h->solve_counts.release(); h->odo_cs.release(); h->pose_cs.release();
     h->gh_ranges.release(); h->gh_bd.release(); h->gh_bx.release(); h->gh_by.release(); h->gh_bxy.release(); h->gh_kmask.release(); h->kmask.release(); h->gh_s2.release(); h->gh_sx.release(); h->gh_sy.release();
     h->gh_rot.release(); h->gh_m.release(); h->gh_nkept.release(); h->gh_boff.release(); h->gh_bk.release(); h->gh_label.release(); h->gh_bloc.release();
     h->gh_st_label.release(); h->gh_misc.release(); h->gh_st_k.release();
@@ -590,8 +589,6 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         HIPCHK(h, h->ms.reserve(3 * (size_t)h->nsuper * L));
         h->ms_clean = false;
     }
-    HIPCHK(h, h->need.reserve((size_t)nloc + 2));
-    HIPCHK(h, hipMemsetAsync(h->need.p, 0, ((size_t)nloc + 2) * sizeof(int), h->stream));   // (epochs start at 1)
     h->solve_epoch = 0;
     h->solve_flag_waves = 0;   // (flags are cleared with the epoch: launch_fused_solve)
     h->ghost_n = 0;
@@ -1236,8 +1233,6 @@ static SolveArgs solve_args(icm_handle* h) {
     a.rot = h->rot.p;
     a.odo_cs = h->odo_cs.p;
     a.cs = h->pose_cs.p;
-    a.need = h->need.p;
-    a.need_seen = h->need.p + h->nloc + 1;
     a.epoch = 0;
     a.ghost_n = h->ghost_n;
     a.ghost_m = h->gh_m.p;
@@ -1251,47 +1246,38 @@ static SolveSeg shard_segment(const icm_handle* h, const int* abort) {
     return SolveSeg{ghost ? (int)h->t_begin - 2 : (int)h->t_begin, (int)(h->t_begin + h->nloc), 0, abort};
 }
 
-// Both colours of the poses [g.t0, g.t1) in one launch (k_solve_m_fused) plus the fix-up launches behind it (poses a
-// fold-only lane left to the complete energy; even waves that deferred), on stream st.
+// Both colours of the poses [g.t0, g.t1) in ONE launch (k_solve_m_fused; lane form), on stream st.  Nothing is queued
+// behind it: poses outside the folded form's range and even waves that deferred are dealt with inside the launch.
 static int launch_fused_solve(icm_handle* h, SolveArgs a, SolveSeg g, hipStream_t st) {
     const int64_t npc = (g.t1 - g.t0) / 2 + 1;   // poses per colour (upper bound)
-    const bool quad = h->solve_quad == 1;   // (automatic = one lane per pose: see icm_sweep_solve)
-    const int ppw = quad ? kWave / 4 : kWave;   // (fewer poses per lane-form wave was measured: 32 at S1 -8 %, 2 at 600 poses +38 %: not adopted)
-    const int nwv = (int)((npc + ppw - 1) / ppw);
+    const int nwv = (int)((npc + kWave - 1) / kWave);   // (fewer poses per lane-form wave was measured: 32 at S1 -8 %, 2 at 600 poses +38 %: not adopted)
     if (h->solve_flag_waves < nwv) {
         HIPCHK(h, hipStreamSynchronize(h->stream));   // (re-allocation: nothing may still be polling the old flags)
         if (h->solve_stream) HIPCHK(h, hipStreamSynchronize(h->solve_stream));
-        HIPCHK(h, h->solve_flags.reserve(2 * (size_t)nwv));
+        HIPCHK(h, h->solve_flags.reserve(2 * (size_t)nwv + 2));
         HIPCHK(h, h->solve_counts.reserve(2));
-        HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, 2 * (size_t)nwv * sizeof(int), st));
+        HIPCHK(h, hipMemsetAsync(h->solve_flags.p, 0, (2 * (size_t)nwv + 2) * sizeof(int), st));
         HIPCHK(h, hipMemsetAsync(h->solve_counts.p, 0, 2 * sizeof(unsigned long long), st));
-        HIPCHK(h, hipMemsetAsync(h->need.p, 0, ((size_t)h->nloc + 2) * sizeof(int), st));
         h->solve_flag_waves = nwv;
         h->solve_epoch = 0;
     }
-    a.epoch = ++h->solve_epoch;   // (flags and marks hold the epoch of the launch that set them: no reset between launches)
+    a.epoch = ++h->solve_epoch;   // (flags and stamps hold the epoch of the launch that set them: no reset between launches)
     int* const deferred = h->solve_flags.p + h->solve_flag_waves;
-    // Fold-only main kernel (thirteen coefficients per pose, no scratch) whenever the folded form can hold at all, i.e.
-    // with isotropic weights; the complete energy in the main kernel otherwise (every pose would go to the fix-up).
+    int* const sync = h->solve_flags.p + 2 * (size_t)h->solve_flag_waves;
+    // Fold-only Nelder-Mead loop (thirteen coefficients per pose) whenever the folded form can hold at all, i.e. with
+    // isotropic weights; the complete energy in the loop otherwise (every pose would be solved twice).
     const bool iso = h->cfg.Q[0] == h->cfg.Q[1] && h->cfg.R[0] == h->cfg.R[1];
     const bool fold = h->fold_mode < 0 ? iso : h->fold_mode == 1;
-    const int nb2 = nblocks_waves(2 * nwv), nb1 = nblocks_waves(nwv);
+    const int nb2 = nblocks_waves(2 * nwv);
     // phase B's matrix, cleared for the next sweep by the launch's waiting even waves (when that is a few dozen stores per
     // lane; else, and after any other solve launch, the next sweep clears it itself: ms_clean)
     const size_t zn = h->path_used == 1 && !h->ms_clean ? 3 * (size_t)h->nsuper * (size_t)h->cfg.L : 0;
     const bool zero_here = zn > 0 && zn <= (size_t)nwv * kWave * 64 && zn < (1ull << 32);
     double* const zo = zero_here ? h->ms.p : nullptr;
-#define FUSED(Q, F) TIMED(h, KID_SOLVE, (k_solve_m_fused<Q, F><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred, zo, (unsigned)(zero_here ? zn : 0))))
-#define FIX(Q, EVEN) TIMED(h, KID_SOLVE_DEFERRED, (k_solve_m_fix<Q><<<nb1, kBlock, 0, st>>>(a, g, nwv, EVEN, deferred, h->solve_counts.p)))
-    if (quad) {
-        if (fold) { FUSED(true, true); FIX(true, 0); } else FUSED(true, false);
-        FIX(true, 1);
-    } else {
-        if (fold) { FUSED(false, true); FIX(false, 0); } else FUSED(false, false);
-        FIX(false, 1);
-    }
-#undef FUSED
-#undef FIX
+    if (fold)
+        TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred, sync, h->solve_counts.p, zo, (unsigned)(zero_here ? zn : 0))));
+    else
+        TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred, sync, h->solve_counts.p, zo, (unsigned)(zero_here ? zn : 0))));
     if (zero_here) h->ms_clean = true;
     HIPCHK(h, hipGetLastError());
     return ICM_OK;
@@ -1329,7 +1315,7 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
         else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_sequential<false><<<1, kWave, 0, h->stream>>>(a)));
         else TIMED(h, KID_SOLVE, (k_solve_m_sequential<<<1, kWave, 0, h->stream>>>(a)));
-    } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->form == 0 && h->fuse_colours) {
+    } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->form == 0 && h->fuse_colours && h->solve_quad != 1) {
         // both colours in one launch, even waves chase the odd ones (a shard: its ghost pose is the first odd pose)
         int rc = launch_fused_solve(h, a, shard_segment(h, abort), h->stream);
         if (rc) return rc;

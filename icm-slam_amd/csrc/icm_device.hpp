@@ -640,7 +640,10 @@ __device__ __forceinline__ double amax3(const Vtx& a, const Vtx& b) {
 // beside SciPy's own termination test: "did anything since the last look disqualify this solve?".  A lane for which it
 // holds leaves the loop and the function returns true for it (its result is discarded by the caller: fold-only
 // solves).  The predicate is asked about the time since the last look so that nothing of it is carried around the
-// loop (a carried flag is a byte in a vector register and five instructions an iteration).
+// loop (a carried flag is a byte in a vector register and five instructions an iteration).  (The second point of an
+// iteration is computed by every lane and used by some: a lane may stop on a point it would have discarded.  Masking
+// the predicate with `can2` was tried in round 4: it makes the flag a carried byte again, +7 instructions an iteration
+// for every pose, to spare the rare pose outside the folded range a second solve.)
 struct NeverStop {
     __device__ __forceinline__ bool operator()() const { return false; }
 };
@@ -773,9 +776,8 @@ __device__ __forceinline__ bool quad_any(bool b) {
     return v != 0;
 }
 
-// (`stop` must be uniform over the quad: its four lanes take every decision together)
-template <class F, class S = NeverStop>
-__device__ __forceinline__ bool nelder_mead3_quad(F f, double sx, double sy, double st, int role, double out[6], S stop = S()) {
+template <class F>
+__device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, double st, int role, double out[6]) {
     const int maxfun = 600, maxiter = 600;
     const double xatol = 1e-3, fatol = 1e-4;
     const double grow = 1 + 0.05;
@@ -799,12 +801,10 @@ __device__ __forceinline__ bool nelder_mead3_quad(F f, double sx, double sy, dou
     // point r of an iteration = ca[r] * xbar + cb[r] * sim[-1]
     const double ca = role == 0 ? 2.0 : (role == 1 ? 3.0 : (role == 2 ? 1.5 : 0.5));
     const double cb = role == 0 ? -1.0 : (role == 1 ? -2.0 : (role == 2 ? -0.5 : 0.5));
-    bool stopped = false;
     while (nfev < maxfun && it < maxiter) {
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
-        stopped = stop();
-        if ((dx <= xatol && df <= fatol) || stopped) break;
+        if (dx <= xatol && df <= fatol) break;
         const double bx = div3((v0.x + v1.x) + v2.x);
         const double by = div3((v0.y + v1.y) + v2.y);
         const double bt = div3((v0.t + v1.t) + v2.t);
@@ -871,10 +871,8 @@ __device__ __forceinline__ bool nelder_mead3_quad(F f, double sx, double sy, dou
         if (aborted) break;
         ++it;
     }
-    stopped = stopped | stop();   // (the evaluations of an iteration that ended on the budgets)
     out[0] = v0.x; out[1] = v0.y; out[2] = v0.t; out[3] = v0.f;
     out[4] = (double)it; out[5] = (double)nfev;
-    return stopped;
 }
 
 }  // namespace icm

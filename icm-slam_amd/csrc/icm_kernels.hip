@@ -2245,10 +2245,7 @@ struct SolveArgs {
                           // moment kernel of the NEXT sweep read (k_pose_rot's values: whoever writes a pose writes its pair)
     const double* odo_cs; // (T,2): (cos, sin) of the odometry headings (k_odo_trig)
     double* cs;           // (T,2): (cos, sin)(theta) of every pose as it stands (k_pose_rot / store_pose_tables / the headers)
-    // fold-only solves (k_solve_m_fused<., true>) and their fix-up (k_solve_m_fix):
-    int* need;            // [nloc + 1], slot tl + 1 (slot 0 = the ghost pose): epoch of the launch that left the pose to the fix-up
-    int* need_seen;       // one word: the latest epoch in which any pose was marked (the fix-up launches look here first)
-    int epoch;
+    int epoch;            // of the one-launch solve (k_solve_m_fused): its flags and deferral stamps hold the epoch that set them
     // ghost pose of a shard (rank > 0): the lower neighbour's last pose t_begin - 1, solved redundantly so that the
     // shard's first even pose needs nothing from another rank in the middle of the sweep (local index tl = -1)
     int ghost_n;          // its kept beams (0: none)
@@ -2570,8 +2567,8 @@ __device__ __forceinline__ void load_pose_in(const SolveArgs& a, int tg, PoseIn&
 }
 
 // FOLD: the Nelder-Mead evaluates the folded form only (pose_energy_fold_only) and the function returns false -- res
-// then means nothing -- as soon as one evaluation of this pose left the form's validity range: the caller marks the
-// pose for the fix-up launch, which repeats the solve with FOLD = false (folded where valid, term by term elsewhere).
+// then means nothing -- as soon as one evaluation it uses left the form's validity range: the caller repeats the
+// solve with FOLD = false (folded where valid, term by term elsewhere).
 // prev = x[:, tg-1] as it stands now; prev_in_table: its (cos, sin) are in the cs table (it was written before this
 // launch began) -- else they are formed here.
 template <bool QUAD, bool FOLD = false>
@@ -2619,17 +2616,17 @@ __device__ __forceinline__ bool solve_pose_in(const SolveArgs& a, int tg, const 
     }
     double out[6];
     if (FOLD) {
-        bool left = false;    // an evaluation since the Nelder-Mead last asked left the folded form's range (quad: of the whole quad)
+        static_assert(!(FOLD && QUAD), "the fold-only solve is the lane form");
+        bool left = false;    // an evaluation since the Nelder-Mead last asked left the folded form's range
         const PinnedTrigK trig;
         auto ef = [&](double px, double py, double th) {
             bool ok;
             const double e = pose_energy_fold_only(f, px, py, th, ok, trig);
-            left |= QUAD ? quad_any(!ok) : !ok;
+            left |= !ok;
             return e;
         };
         auto stop = [&]() { const bool l = left; left = false; return l; };
-        const bool stopped = QUAD ? nelder_mead3_quad(ef, sx, sy, st, role, out, stop) : nelder_mead3(ef, sx, sy, st, out, stop);
-        if (stopped) return false;
+        if (nelder_mead3(ef, sx, sy, st, out, stop)) return false;
     } else if (QUAD) {
         nelder_mead3_quad([&](double px, double py, double th) { return pose_energy_moments(c, m, f, px, py, th); }, sx, sy, st, role, out);
     } else {
@@ -2694,34 +2691,37 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, SolveSeg
 // per-wave flag; waves [nw, 2 nw) poll the two flags they depend on, then solve the even poses.
 //
 // Forward progress does NOT rest on dispatch order: an even wave polls at most `spin_limit`
-// times; if its flags have not arrived by then it marks itself in `deferred[]`, touches nothing
-// and exits (freeing its slot for whatever odd waves are still waiting to be dispatched).
-// k_solve_m_fix, launched right behind on the same stream, solves exactly the marked waves
-// -- behind the kernel boundary every odd pose is final -- and clears the marks.  With the
-// observed dispatch (lower workgroup ids first) no wave ever defers and that launch is empty;
-// under any other dispatch order the sweep is slower, never wrong and never stuck.
+// times; if its flags have not arrived by then it stamps `deferred[]`, touches nothing and is done
+// (freeing its slot for whatever odd waves are still waiting to be dispatched).  Every wave ends
+// with one atomic increment of sync[0]; the wave that finds itself LAST -- every odd pose is final
+// then -- solves the waves that deferred, one after the other, inside this launch (round 3 queued
+// two fix-up launches behind every solve launch for this and for the poses outside the folded
+// form: 2 x 5 us of empty launches per sweep).  With the observed dispatch (lower workgroup ids
+// first) no wave ever defers; under any other order the sweep is slower, never wrong, never stuck.
 // Hand-off per MI355X_MICROARCH.md (valid forms): producer = write-through (sc1, agent-scope) stores of the
 // poses, vmcnt(0), relaxed agent flag store -- no cache-wide release (782 odd waves each writing back their
 // XCD's whole L2 queued behind one another: the even waves started 19 us after their flags' poses were
 // final); consumer = relaxed polls, ONE agent acquire fence, vmcnt(0), then plain loads.  The odd waves that READ an even wave's poses (as the old values of
 // their neighbours) are exactly the two it waits for, so nothing is overwritten while in use.
-// QUAD: the latency form (one DPP quad per pose, 16 poses per wave) with the same dependency rule.
 //
 // FOLD: the lanes evaluate the folded form of the energy ONLY (thirteen coefficients per pose, no context, no
-// moment sums, no scratch).  A pose one of whose evaluations leaves the form's validity range is not stored:
-// its lane writes the launch's epoch into need[] (write-through, like a pose) and the fix-up launches solve it
-// with the complete energy.  An even pose next to a marked odd one cannot be solved here either (its neighbour
-// is not final): it marks itself too.  Marking is decided per pose from the pose's own data, and the fix-up
-// runs the arithmetic the FOLD = false kernel runs, so the sweep's result does not depend on which road a pose took.
+// moment sums live across the Nelder-Mead loop).  A pose one of whose evaluations leaves the form's validity range
+// is solved once more, on the spot, with the complete energy (folded where valid, term by term elsewhere: what the
+// FOLD = false kernel runs) -- a cold block behind the loop that reloads everything from memory, so the loop's own
+// registers are what they were; the wave publishes its poses after it.  Which road a pose takes is decided from the
+// pose's own data and both evaluate identical arithmetic: the sweep's result does not depend on it.
+//   sync[0]: waves of this launch that are done (the last one resets it), sync[1]: waves that deferred in this launch
+//   counts[0] += even waves that deferred, counts[1] += poses solved with the complete energy behind the folded loop
 #ifdef ICM_WAVE_TS   // measurement builds only (tools/wave_timeline.py): per-wave start / go / end times
 __device__ unsigned long long g_wave_ts[4 * 16384];
 #define WAVE_TS(slot) do { if (lane == 0 && gw < 16384) g_wave_ts[4 * gw + (slot)] = wall_clock64(); } while (0)
 #else
 #define WAVE_TS(slot) do { } while (0)
 #endif
-template <bool QUAD, bool FOLD>
-__global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags,
-                                                          int spin_limit, int* __restrict__ deferred,
+template <bool FOLD>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags,
+                                                          int spin_limit, int* __restrict__ deferred, int* __restrict__ sync,
+                                                          unsigned long long* __restrict__ counts,
                                                           double* __restrict__ zero_out = nullptr, unsigned zero_n = 0) {
     const int lane = lane_id();
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -2739,18 +2739,16 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
     const int epoch = a.epoch;
     const bool even = gw >= nw;
     const int wv = even ? gw - nw : gw;
-    constexpr int PPW = QUAD ? kWave / 4 : kWave;   // poses per wave
-    const int role = QUAD ? (lane & 3) : 0;
-    const int tg = seg_pose(g, even, wv * PPW + (QUAD ? lane >> 2 : lane));
-    const bool mine = tg < g.t1;   // (whole quads together)
+    const int tg = seg_pose(g, even, wv * kWave + lane);
+    const bool mine = tg < g.t1;
     WAVE_TS(0);
     // everything this launch does not write -- moment sums, odometry, controls, the pose's own previous value and the
     // trigonometry kept beside them -- is requested BEFORE an even wave starts to wait for its odd neighbours
     PoseIn in;
     in.n = 0;
-    if (mine) load_pose_in(a, tg, in);
+    if (FOLD && mine) load_pose_in(a, tg, in);
+    int ready = 1;
     if (even) {
-        int ready = 1;
         unsigned zq = (unsigned)wv * kWave + lane;   // this lane's next word of zero_out
         const unsigned zstride = (unsigned)nw * kWave;
         for (int d = 0; d < 2 && ready; ++d) {   // the (at most) two odd waves that hold this wave's neighbours
@@ -2775,85 +2773,98 @@ __global__ __launch_bounds__(kBlock) void k_solve_m_fused(SolveArgs a, SolveSeg 
         }
         if (zero_out)
             for (; zq < zero_n; zq += zstride) zero_out[zq] = 0.0;   // (what the wait left over)
-        if (!ready) {
-            if (lane == 0) deferred[wv] = 1;   // (read by the next launch: a kernel boundary, no fence needed)
-            return;                             // wave-uniform: x is left untouched
+        if (!ready) {   // wave-uniform: x is left untouched
+            if (lane == 0) {
+                __hip_atomic_store(&deferred[wv], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&counts[0], 1ull);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stamp and count are out before this wave counts as done)
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     WAVE_TS(1);
-    bool solved = false;
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;   // (three scalars, not an array: an array that lives across the branches goes to scratch)
-    if (mine) {
-        const int q = tg - a.t_begin + 1;   // slot of need[]
-        solved = true;
-        if (FOLD && even) {   // a neighbour left to the fix-up is not final
-            const bool dep = (a.need[q - 1] == epoch) | (tg + 1 < g.t1 && a.need[q + 1] == epoch);
-            solved = !dep;
+    bool redo = ready && mine;             // lanes whose pose the block below solves with the complete energy
+    if (FOLD && redo) {
+        double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
+        // an odd pose's lower neighbour is an OLD even pose (its pair is in the table); an even pose's was written a
+        // moment ago by an odd wave of this launch, which publishes the pose, not the pair
+        redo = !solve_pose_in<false, true>(a, tg, in, prev, !even, r0, r1, r2);   // (false: an evaluation left the folded form's range)
+    }
+    // The complete-energy solve, everything reloaded from memory (tgc is opaque to the compiler, so nothing of it is
+    // shared with -- kept alive across -- the folded loop above).  First pass: this wave's own poses (FOLD: the rare ones
+    // outside the folded range; else all of them), then the hand-off.  Further passes: only in the wave that finishes
+    // the launch last, one per even wave that deferred.
+    int tgc = tg;
+    bool first = true, prev_tab = !even;
+    int scan_from = 0;
+    for (;;) {
+        const unsigned long long mredo = __ballot(redo);
+        if (mredo != 0ull) {
+            asm volatile("" : "+v"(tgc));
+            if (redo) {
+                double prev[3] = {a.x[3 * (size_t)(tgc - 1)], a.x[3 * (size_t)(tgc - 1) + 1], a.x[3 * (size_t)(tgc - 1) + 2]};
+                double res[3];
+                solve_pose_moments<false, false>(a, tgc, prev, prev_tab, res);
+                r0 = res[0]; r1 = res[1]; r2 = res[2];
+            }
+            if (FOLD && first && lane == (int)__builtin_ctzll(mredo)) atomicAdd(&counts[1], (unsigned long long)__popcll(mredo));
         }
-        if (solved) {
-            double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
-            // an odd pose's lower neighbour is an OLD even pose (its pair is in the table); an even pose's was written a
-            // moment ago by an odd wave of this launch, which publishes the pose, not the pair
-            solved = solve_pose_in<QUAD, FOLD>(a, tg, in, prev, !even, r0, r1, r2, role);
-        }
-        if (role == 0) {
+        if (!first) {   // a deferred wave's poses: nobody in this launch waits for them
+            if (redo) {
+                const double res[3] = {r0, r1, r2};
+                store_pose(a, tgc, res, false);
+            }
+        } else {
             // (odd poses are handed to the even waves of this launch: write-through (sc1) stores, no cache-wide release needed)
-            if (solved) {
+            if (ready && mine) {
                 const double res[3] = {r0, r1, r2};
                 store_pose_xyz(a, tg, res, !even);
-            } else {
-                __hip_atomic_store(&a.need[q], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.need_seen, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (every writer stores the same value)
             }
+            WAVE_TS(2);
+            if (!even) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every write-through store of this wave has been acknowledged
+                if (lane == 0) __hip_atomic_store(&flags[wv], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                WAVE_TS(3);
+            }
+            // done: one increment per wave, issued here -- everything a later reader INSIDE this launch needs of this wave
+            // (an odd wave's poses, a deferral stamp) went out write-through and is acknowledged -- and looked at behind
+            // the rotation pairs, whose ~260 instructions hide its round trip
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the rotation pairs kept beside the poses are next sweep's business: behind the hand-off
+            if (ready && mine) store_pose_tables(a, tg, r2);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != 2 * nw - 1) return;
+            int nd = 0;
+            if (lane == 0) {   // the last wave of the launch: the counters are the next launch's again
+                nd = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sync[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            nd = __builtin_amdgcn_readfirstlane(nd);
+            if (nd == 0) return;
+            // waves deferred (never seen under the in-order dispatch of this chip): every odd pose is final and visible
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            first = false;
+            prev_tab = false;   // (an even pose's lower neighbour was written in this launch: its pair may not be out yet)
         }
-    }
-    WAVE_TS(2);
-    if (!even) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every write-through store of this wave has been acknowledged
-        if (lane == 0) __hip_atomic_store(&flags[wv], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        WAVE_TS(3);
-    }
-    // the rotation pairs kept beside the poses are next sweep's business: behind the hand-off
-    if (mine && solved && role == 0) store_pose_tables(a, tg, r2);
-}
-
-// The fix-up launches behind k_solve_m_fused, one per colour (odd first): the poses a fold-only lane marked in
-// need[] and -- even colour -- the waves that deferred, solved with the complete energy.  Normally nothing is marked
-// and no wave deferred: every wave returns after two scalar loads.
-//   counts[0] += even waves that had deferred, counts[1] += poses solved here because they were marked
-template <bool QUAD>
-__global__ __launch_bounds__(kBlock) void k_solve_m_fix(SolveArgs a, SolveSeg g, int nw, int even, int* __restrict__ deferred,
-                                                        unsigned long long* __restrict__ counts) {
-    const int lane = lane_id();
-    const int wv = blockIdx.x * kWavesPerBlock + wave_in_block();
-    if (wv >= nw) return;
-    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;
-    const bool wdef = even && deferred[wv] != 0;
-    const bool marks = *a.need_seen == a.epoch;
-    if (!wdef && !marks) return;
-    constexpr int PPW = QUAD ? kWave / 4 : kWave;
-    const int role = QUAD ? (lane & 3) : 0;
-    const int j = wv * PPW + (QUAD ? lane >> 2 : lane);
-    const int tg = seg_pose(g, even != 0, j);
-    bool mine = false;
-    if (tg < g.t1) {
-        mine = wdef || a.need[tg - a.t_begin + 1] == a.epoch;
-        if (mine) {
-            double prev[3] = {a.x[3 * (size_t)(tg - 1)], a.x[3 * (size_t)(tg - 1) + 1], a.x[3 * (size_t)(tg - 1) + 2]};
-            double res[3];
-            solve_pose_moments<QUAD, false>(a, tg, prev, true, res, role);
-            if (role == 0) store_pose(a, tg, res, false);
+        // the next wave that deferred in this launch
+        int found = -1;
+        for (int q0 = scan_from; q0 < nw && found < 0; q0 += kWave) {
+            const int q = q0 + lane;
+            const int d = q < nw ? __hip_atomic_load(&deferred[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const unsigned long long m = __ballot(d == epoch);
+            if (m) found = q0 + (int)__builtin_ctzll(m);
         }
-    }
-    const unsigned long long nm = __ballot(mine && role == 0 && !wdef);
-    if (lane == 0) {
-        if (wdef) {
-            deferred[wv] = 0;
-            atomicAdd(&counts[0], 1ull);
-        }
-        if (nm) atomicAdd(&counts[1], (unsigned long long)__popcll(nm));
+        if (found < 0) return;
+        scan_from = found + 1;
+        tgc = seg_pose(g, true, found * kWave + lane);
+        redo = tgc < g.t1;
     }
 }
 

@@ -469,7 +469,7 @@ class SweepEngine:
 
     def set_fold_mode(self, mode):
         """-1 automatic, 1 the one-launch solve evaluates the folded energy only and leaves poses outside its range to
-        the fix-up launches, 0 the complete energy in the main kernel (icm_set_fold_mode)."""
+        a second solve by the same wave, 0 the complete energy in the loop itself (icm_set_fold_mode)."""
         self._chk(self.lib.icm_set_fold_mode(self.h, int(mode)))
 
     def set_assoc_persistence(self, workgroups_per_cu):
@@ -477,17 +477,17 @@ class SweepEngine:
         self._chk(self.lib.icm_set_assoc_persistence(self.h, int(workgroups_per_cu)))
 
     def fixup_poses(self):
-        """Poses the fix-up launches solved because a fold-only lane marked them, so far."""
+        """Poses solved a second time with the complete energy (an evaluation left the folded form's range), so far."""
         n = C.c_int64(0)
         self._chk(self.lib.icm_get_fixup_poses(self.h, C.byref(n)))
         return int(n.value)
 
     def set_fused_spin_limit(self, polls):
-        """Polls an even wave of the one-launch solve waits before deferring to the fix-up launch."""
+        """Polls an even wave of the one-launch solve waits before deferring to the launch's last wave."""
         self._chk(self.lib.icm_set_fused_spin_limit(self.h, int(polls)))
 
     def fused_deferred(self):
-        """Even waves that deferred to the fix-up launch so far (normally 0)."""
+        """Even waves that deferred so far (normally 0)."""
         n = C.c_int64(0)
         self._chk(self.lib.icm_get_fused_deferred(self.h, C.byref(n)))
         return int(n.value)

@@ -34,9 +34,9 @@ int icm_get_solve_diag(icm_handle *h, double *out);
  * Forms 1 and 2 exist to cross-check form 0. */
 int icm_set_energy_form(icm_handle *h, int form);
 
-/* Lanes per pose in the red-black solves: 0 = one lane per pose (throughput form), 1 = one DPP
- * quad per pose evaluating the four candidate points of a Nelder-Mead iteration at once (latency
- * form, for colours with fewer poses than the chip has lanes), -1 = automatic (default).
+/* Lanes per pose in the red-black solves: 0 / -1 (default) = one lane per pose (throughput form, both colours in one
+ * launch), 1 = one DPP quad per pose evaluating the four candidate points of a Nelder-Mead iteration at once (latency
+ * form, kept as a cross-check: one launch per colour; measured slower at every size since the folded energy).
  * Bit-identical results. */
 int icm_set_solve_lanes(icm_handle *h, int mode);
 
@@ -45,24 +45,22 @@ int icm_set_solve_lanes(icm_handle *h, int mode);
  * (k_solve_m_fused); 0 = one launch per colour.  Bit-identical results. */
 int icm_set_colour_fusion(icm_handle *h, int on);
 /* How many times an even wave of the one-launch solve polls for its odd neighbours (~0.2 us per
- * poll; default 1 << 17) before it DEFERS: it leaves its poses untouched and the fix-up launch
- * queued right behind (k_solve_m_fix) solves them after the kernel boundary.  Forward
- * progress therefore never depends on the order workgroups are dispatched in; 0 defers every wave
- * whose neighbours are not done at its first look (= one launch per colour, through the same
- * code).  Bit-identical results for every value.  icm_get_fused_deferred: waves deferred so far
- * over the handle's life (synchronises the stream). */
+ * poll; default 1 << 17) before it DEFERS: it leaves its poses untouched, and the wave of the launch
+ * that finishes last -- every odd pose is final then -- solves the deferred waves before the launch
+ * ends.  Forward progress therefore never depends on the order workgroups are dispatched in; 0 defers
+ * every wave whose neighbours are not done at its first look.  Bit-identical results for every value.
+ * icm_get_fused_deferred: waves deferred so far over the handle's life (synchronises the stream). */
 int icm_set_fused_spin_limit(icm_handle *h, int polls);
 int icm_get_fused_deferred(icm_handle *h, int64_t *waves);
 
-/* What the one-launch solve evaluates per Nelder-Mead step (fun_xn / fun_x, scripts/ICM_ROS.py:220-278):
+/* What the Nelder-Mead loop of the one-launch solve evaluates (fun_xn / fun_x, scripts/ICM_ROS.py:220-278):
  *   1  the FOLDED form only -- the whole conditional energy as one quadratic in the planar step with 13 per-pose
  *      coefficients (valid per pose while its heading step stays within 0.25 rad and no angle residual can wrap); a
- *      pose one of whose evaluations leaves that range is not stored but marked, and the fix-up launches behind
- *      (k_solve_m_fix, odd then even) solve it -- and the even poses next to a marked odd pose -- with
- *   0  the complete energy (folded where valid, term by term elsewhere) in the main kernel itself;
+ *      pose one of whose evaluations leaves that range is solved once more on the spot, by the same wave, with
+ *   0  the complete energy (folded where valid, term by term elsewhere) in the loop itself;
  *  -1  (default) 1 with isotropic weights Q0 == Q1, R0 == R1, else 0 (the folded form never holds then).
  * Which road a pose takes is decided from its own data and both evaluate identical arithmetic: bit-identical results.
- * icm_get_fixup_poses: poses solved by the fix-up launches because they were marked, over the handle's life. */
+ * icm_get_fixup_poses: poses that needed the second solve, over the handle's life. */
 int icm_set_fold_mode(icm_handle *h, int mode);
 int icm_get_fixup_poses(icm_handle *h, int64_t *poses);
 

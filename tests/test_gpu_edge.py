@@ -614,15 +614,16 @@ def _s1_state_after(sweeps, setup):
 def test_fused_solve_defers_instead_of_depending_on_dispatch_order():
     """The one-launch red-black solve must not need its odd waves to be dispatched first: an even
     wave that does not see its neighbours' flags within the poll budget leaves its poses alone and
-    the fix-up launch behind it solves them.  With a budget of 0 polls nearly every even wave takes
-    that road -- the result is bit-identical to the default and to one launch per colour, and the
-    default run defers nothing."""
+    the wave that finishes the launch last solves them (inside the same launch: nothing is queued
+    behind a solve launch).  With a budget of 0 polls nearly every even wave takes that road -- the
+    result is bit-identical to the default, to one launch per colour and to the quad form (which
+    always runs one launch per colour), and the default run defers nothing."""
     (ref, nd_ref) = _s1_state_after(3, lambda e: None)
     (two, _) = _s1_state_after(3, lambda e: e.set_colour_fusion(False))
     (zero, nd_zero) = _s1_state_after(3, lambda e: e.set_fused_spin_limit(0))
     (quad0, nd_q) = _s1_state_after(3, lambda e: (e.set_solve_lanes(1), e.set_fused_spin_limit(0)))
-    print("even waves deferred: default %d, 0 polls %d (lane form) / %d (quad form)" % (nd_ref, nd_zero, nd_q))
-    assert nd_ref == 0 and nd_zero > 0 and nd_q > 0
+    print("even waves deferred: default %d, 0 polls %d (lane form) / %d (quad form: one launch per colour)" % (nd_ref, nd_zero, nd_q))
+    assert nd_ref == 0 and nd_zero > 0 and nd_q == 0
     for other in (two, zero, quad0):
         for a, b in zip(ref, other):
             assert np.array_equal(a, b)
@@ -814,9 +815,10 @@ def test_non_finite_inputs_do_not_hang():
 
 
 def test_fold_only_solve_with_fixup_is_bit_identical():
-    """The one-launch solve in its fold-only form (13 coefficients per pose, no scratch; poses outside the folded
-    form's range left to the fix-up launches) against the complete energy in the main kernel: S1 over 6 sweeps with
-    state reads, snapshot / restore and host-array sweeps in between -- every state bit-equal."""
+    """The one-launch solve in its fold-only form (13 coefficients per pose in the Nelder-Mead loop; a pose outside
+    the folded form's range solved once more by its wave with the complete energy) against the complete energy in the
+    loop itself: S1 over 6 sweeps with state reads, snapshot / restore and host-array sweeps in between -- every
+    state bit-equal."""
     from ICM_SLAM_tools import ConfigICM
     from icmslam_hip import SweepEngine
     from icmslam_hip.synthetic import WORKLOADS, make_workload
@@ -848,7 +850,7 @@ def test_fold_only_solve_with_fixup_is_bit_identical():
     ref, _, nf0 = run(0)
     got, nd, nf1 = run(1)
     auto, _, nfa = run(-1)
-    print("fold-only S1: even waves deferred %d, poses solved by the fix-up launches %d (automatic mode: %d)" % (nd, nf1, nfa))
+    print("fold-only S1: even waves deferred %d, poses solved a second time %d (automatic mode: %d)" % (nd, nf1, nfa))
     assert nf0 == 0 and nfa == nf1      # isotropic weights: automatic = fold-only
     for a, b, c in zip(ref, got, auto):
         for u, v, w in zip(a, b, c):
@@ -859,10 +861,10 @@ def test_fold_only_solve_with_fixup_is_bit_identical():
 
 def test_fixup_launches_take_poses_outside_the_folded_range():
     """Poses whose heading is off by 0.4 rad start their solve outside the folded form's range (|d theta| <= 0.25):
-    the fold-only kernel must leave exactly those -- and the even poses next to a marked odd one -- to the fix-up
-    launches, and the sweep must equal the one with the complete energy in the main kernel, bit for bit, and the C
-    oracle to 1e-9.  Same with anisotropic weights forced through the fold-only kernel (the folded form never holds:
-    every solved pose goes through the fix-up launches)."""
+    the fold-only kernel must solve exactly those -- and whatever their kick pushes out of range around them -- a
+    second time with the complete energy, and the sweep must equal the one with the complete energy in the loop
+    itself, bit for bit, and the C oracle to 1e-9.  Same with anisotropic weights forced through the fold-only kernel
+    (the folded form never holds: every solved pose is solved twice)."""
     from ICM_SLAM_tools import ConfigICM
     from icmslam_hip import SweepEngine
     from icmslam_hip.synthetic import make_workload
@@ -887,10 +889,10 @@ def test_fixup_launches_take_poses_outside_the_folded_range():
             outs[mode] = (eng.get_state(), eng.fixup_poses())
             eng.close()
         (ref, n0), (got, n1) = outs[0], outs[1]
-        print("%s: poses solved by the fix-up launches %d (of %d pose solves)" % (what, n1, 2 * (wl.T - 1)))
+        print("%s: poses solved a second time %d (of %d pose solves)" % (what, n1, 2 * (wl.T - 1)))
         assert n0 == 0
         if what == "kicked headings":
-            assert 30 <= n1 < 400                  # the kicked poses and their even neighbours, not the sequence
+            assert 30 <= n1 < 400                  # the kicked poses and their neighbours, not the sequence
         else:
             assert n1 >= 0.7 * 2 * (wl.T - 1)        # everything but the no-beam odd poses of the turn (they need no energy)
         for u, v in zip(ref, got):
@@ -907,10 +909,11 @@ def test_fixup_launches_take_poses_outside_the_folded_range():
 
 
 def test_fixup_launches_with_deferred_waves_and_quad_form():
-    """The fix-up launches carry two kinds of work at once: poses a fold-only lane marked and even waves that deferred.
-    With the poll budget at 0 EVERY even wave whose odd neighbours are not done at its first look defers; with kicked
-    headings some odd poses are marked on top of that -- lane form and quad form, all against the complete-energy kernel
-    with the default poll budget: bit-identical."""
+    """Both rare roads of the one-launch solve at once: poses outside the folded form's range (solved a second time by
+    their wave) and even waves that deferred (solved by the launch's last wave).  With the poll budget at 0 EVERY even
+    wave whose odd neighbours are not done at its first look defers; with kicked headings some poses leave the folded
+    range on top of that -- lane form, and the quad form (one launch per colour) beside it, all against the
+    complete-energy kernel with the default poll budget: bit-identical."""
     from ICM_SLAM_tools import ConfigICM
     from icmslam_hip import SweepEngine
     from icmslam_hip.synthetic import make_workload
@@ -932,8 +935,8 @@ def test_fixup_launches_with_deferred_waves_and_quad_form():
             eng.sweep_device("redblack")
         outs.append((eng.get_state(), eng.fused_deferred(), eng.fixup_poses()))
         eng.close()
-    print("deferred waves / fix-up poses per configuration:", [(o[1], o[2]) for o in outs])
-    assert outs[1][1] > 0 and outs[1][2] > 0, "both kinds of fix-up work occurred together"
+    print("deferred waves / poses solved twice per configuration:", [(o[1], o[2]) for o in outs])
+    assert outs[1][1] > 0 and outs[1][2] > 0, "both rare roads were taken in the same launches"
     for o in outs[1:]:
         for a, b in zip(outs[0][0], o[0]):
             assert np.array_equal(a, b)
@@ -956,7 +959,7 @@ def test_fold_only_solve_on_the_dataset_sequential_and_redblack():
             eng.sweep_device("redblack")
         res.append((eng.get_state(), eng.fixup_poses()))
         eng.close()
-    print("data_IJAC2018: poses solved by the fix-up launches over 3 sweeps: %d" % res[1][1])
+    print("data_IJAC2018: poses solved a second time over 3 sweeps: %d" % res[1][1])
     for a, b in zip(res[0][0], res[1][0]):
         assert np.array_equal(a, b)
 
