@@ -129,21 +129,24 @@ class ICM_ROS(ROS):
     # the hot path
     # ------------------------------------------------------------------------------------
     def _sequence_key(self):
-        """Identity of the uploaded sequence: shapes, buffer addresses and cheap checksums of all
-        three arrays.  The reference reads `mediciones`, `odometria` and `u` afresh on every call
-        (scripts/ICM_ROS.py:127-158); replacing any of them -- also by a same-shaped array that lands
-        at a recycled address -- must reach the device copy."""
+        """Identity of the uploaded sequence: the array objects, their shapes and buffer addresses, and a checksum of a
+        strided sample of each (a few microseconds per call).  The reference reads `mediciones`, `odometria` and `u`
+        afresh on every call (scripts/ICM_ROS.py:127-158); here they are uploaded and pre-filtered once, so REPLACING any
+        of them (also by a same-shaped array at a recycled address) re-uploads, and so does an in-place edit that touches
+        a sampled column (16 scans, every 256th odometry / control sample, first and last always) -- an in-place edit
+        elsewhere must be announced with invalidate_sequence().  (Documented in INTEGRATION.md; a full checksum of
+        `mediciones` would read 576 MB per sweep at the headline size.)"""
         m, o, u = self.mediciones, self.odometria, self.u
 
-        def chk(a, cols):   # strided column sample (first and last column always in): microseconds per call
+        def chk(a, cols):
             if a.ndim != 2 or not a.size:
                 return 0.0
             step = max(1, a.shape[1] // cols)
             return float(a[:, ::step].sum()) + float(a[:, -1].sum())
 
-        return (m.shape, o.shape, u.shape,
+        return (id(m), id(o), id(u), m.shape, o.shape, u.shape,
                 m.__array_interface__["data"][0], o.__array_interface__["data"][0], u.__array_interface__["data"][0],
-                chk(m, 64), chk(o, 2048), chk(u, 2048))
+                chk(m, 16), chk(o, 256), chk(u, 256))
 
     def _get_engine(self):
         key = self._sequence_key()

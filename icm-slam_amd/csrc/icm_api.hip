@@ -180,9 +180,28 @@ struct icm_handle {
     int form = 0;  // 0 moments (lane per pose), 1 per beam, 2 per entry (wave per pose)
     int *pin_i = nullptr, *pin_i_dev = nullptr;   // pinned host words and their device-side address
     double* pin_d = nullptr;  // pinned staging: raw map download (3L)
+    double *pin_map = nullptr, *pin_map_dev = nullptr;   // mapped, pinned [x (L) | y (L) | counters (L)]: the refined map straight from k_fl_finalize (icm_sweep)
+    bool host_map_wanted = false;   // this sweep's Mapa.filtrar writes pin_map as well
     DevBuf<double> pack;         // refined map + counters packed for one download
     std::vector<double> h_pack;
     DevBuf<double> x_rows;       // (3,T) staging of the caller's pose layout (transposed to / from (T,3) on the device)
+    struct Pinned { char* host; size_t bytes; char* dev; };
+    std::vector<Pinned> pinned;  // caller-owned host ranges registered with the runtime (icm_pin_host): kernels read / write them in place
+    // The drop-in call on a registered pose array (icm_sweep): the solves write every pose into the caller's array as well
+    // (x_mirror, SolveArgs::xh), so there is no download; and when the caller hands back the array the last call filled,
+    // there is no upload either -- a side-stream kernel checks, under phase A, that host and device poses still agree
+    // (k_x_compare: stale word := x_epoch if not, and then solves and Mapa.filtrar leave everything alone and the call
+    // starts over with an upload).
+    double* x_mirror = nullptr;      // device-side address of the caller's (3,T) array for THIS call (null: none)
+    const double* mirror_host = nullptr;   // the host array whose contents equal the device poses (as far as this library knows)
+    DevBuf<int> x_stale;             // [1]: the epoch of the call whose check failed
+    int x_epoch = 0;
+    int64_t dropin_counts[3] = {0, 0, 0};   // icm_sweep calls: [0] started without an upload, [1] of those: the check failed (started over), [2] poses mirrored into the caller's array
+    double h_x0[3] = {0, 0, 0};      // host copy of x0 as uploaded
+    bool x_mirrored = false;         // the sweep's solve launch wrote the poses into x_mirror
+    bool x_check = false;            // this sweep runs from the device's poses on the strength of a check still in flight (ev_cmp)
+    bool x_check_wait = false;       // ... which the solve launch has not been ordered behind yet
+    hipEvent_t ev_cmp = nullptr;
     bool dev_map_current = false;   // the device search structures hold exactly h_map (K, lact)
     std::vector<double> h_yraw, h_cntraw;
     bool raw_on_device = false;   // y_raw / cnt_raw of the last sweep have not been copied to h_yraw / h_cntraw yet
@@ -336,9 +355,12 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
         (e = create_solve_stream(&h->solve_stream)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->ev_map, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->ev_cmp, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&h->ev_gh0, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&h->ev_gh1, hipEventDisableTiming)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_i), 64 * sizeof(int), hipHostMallocMapped)) != hipSuccess ||
         (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_i_dev), h->pin_i, 0)) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_map), (size_t)(3 * cfg->L) * sizeof(double), hipHostMallocMapped)) != hipSuccess ||
+        (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_map_dev), h->pin_map, 0)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_d), (size_t)(3 * cfg->L + 16 + 64) * sizeof(double))) != hipSuccess) {
         g_create_err = std::string("icm_create: ") + hipGetErrorString(e);
         delete h;
@@ -394,12 +416,17 @@ int icm_destroy(icm_handle* h) {
     h->gh_ranges.release(); h->gh_bd.release(); h->gh_bx.release(); h->gh_by.release(); h->gh_bxy.release(); h->gh_kmask.release(); h->kmask.release(); h->gh_s2.release(); h->gh_sx.release(); h->gh_sy.release();
     h->gh_rot.release(); h->gh_m.release(); h->gh_nkept.release(); h->gh_boff.release(); h->gh_bk.release(); h->gh_label.release(); h->gh_bloc.release();
     h->gh_st_label.release(); h->gh_misc.release(); h->gh_st_k.release();
+    if (h->ev_cmp) (void)hipEventDestroy(h->ev_cmp);
+    h->x_stale.release();
     if (h->ev_gh0) (void)hipEventDestroy(h->ev_gh0);
     if (h->ev_gh1) (void)hipEventDestroy(h->ev_gh1);
     h->snap.x.release(); h->snap.mapx.release(); h->snap.mapy.release(); h->snap.counts_new.release();
     h->snap.g_cell.release(); h->snap.g_lm.release(); h->snap.g_nb.release(); h->snap.gpar.release();
+    for (auto& pr : h->pinned) (void)hipHostUnregister(pr.host);
+    h->pinned.clear();
     if (h->pin_i) (void)hipHostFree(h->pin_i);
     if (h->pin_d) (void)hipHostFree(h->pin_d);
+    if (h->pin_map) (void)hipHostFree(h->pin_map);
     h->x_rows.release(); h->pack.release();
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     h->own_stats_all.release(); h->own_stats_send.release(); h->own_poses.release();
@@ -443,6 +470,61 @@ __global__ __launch_bounds__(256) void k_x_poses_to_rows(const double* __restric
     rows[t] = x[3 * (size_t)t];
     rows[(size_t)T + t] = x[3 * (size_t)t + 1];
     rows[2 * (size_t)T + t] = x[3 * (size_t)t + 2];
+}
+
+// Device-side address of a caller's host range that lies inside a range registered by icm_pin_host (null: not registered).
+static double* pinned_alias(const icm_handle* h, const void* p, size_t bytes) {
+    const char* c = static_cast<const char*>(p);
+    for (const auto& pr : h->pinned)
+        if (c >= pr.host && c + bytes <= pr.host + pr.bytes) return reinterpret_cast<double*>(pr.dev + (c - pr.host));
+    return nullptr;
+}
+
+int icm_pin_host(icm_handle* h, void* ptr, size_t bytes) {
+    if (!h) return ICM_ERR_ARG;
+    if (!ptr || !bytes) FAIL(h, ICM_ERR_ARG, "icm_pin_host: null range");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (pinned_alias(h, ptr, bytes)) return ICM_OK;
+    for (const auto& pr : h->pinned)
+        if (static_cast<char*>(ptr) < pr.host + pr.bytes && pr.host < static_cast<char*>(ptr) + bytes)
+            FAIL(h, ICM_ERR_ARG, "icm_pin_host: the range overlaps a registered one (icm_unpin_host it first)");
+    void* dev = nullptr;
+    HIPCHK(h, hipHostRegister(ptr, bytes, hipHostRegisterMapped));
+    hipError_t e = hipHostGetDevicePointer(&dev, ptr, 0);
+    if (e != hipSuccess) {
+        (void)hipHostUnregister(ptr);
+        FAIL(h, ICM_ERR_HIP, std::string("icm_pin_host: hipHostGetDevicePointer: ") + hipGetErrorString(e));
+    }
+    h->pinned.push_back({static_cast<char*>(ptr), bytes, static_cast<char*>(dev)});
+    return ICM_OK;
+}
+
+int icm_unpin_host(icm_handle* h, void* ptr) {
+    if (!h) return ICM_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (size_t i = 0; i < h->pinned.size(); ++i)
+        if (h->pinned[i].host == static_cast<char*>(ptr)) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));   // (a kernel may still be writing into it)
+            HIPCHK(h, hipHostUnregister(ptr));
+            h->pinned.erase(h->pinned.begin() + (long)i);
+            h->mirror_host = nullptr;
+            return ICM_OK;
+        }
+    FAIL(h, ICM_ERR_ARG, "icm_unpin_host: not a registered range");
+}
+
+// Do the caller's (3,T) poses (registered host memory, read over PCIe) still equal the device's (T,3) ones, bit for bit?
+__global__ __launch_bounds__(256) void k_x_compare(const double* __restrict__ rows, const double* __restrict__ x, int T,
+                                                   int* __restrict__ stale_dev, int* __restrict__ stale_host, int epoch) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const unsigned long long* r = reinterpret_cast<const unsigned long long*>(rows);
+    const unsigned long long* d = reinterpret_cast<const unsigned long long*>(x);
+    const bool differ = r[t] != d[3 * (size_t)t] || r[(size_t)T + t] != d[3 * (size_t)t + 1] || r[2 * (size_t)T + t] != d[3 * (size_t)t + 2];
+    if (differ) {
+        *stale_dev = epoch;
+        *stale_host = epoch;
+    }
 }
 
 int icm_upload(icm_handle* h, const double* ranges, const double* odo, const double* u, const double* cosb,
@@ -682,9 +764,13 @@ static int set_state_impl(icm_handle* h, const double* x, const double* x0, cons
         h->x = h->x_own.p;
     }
     HIPCHK(h, h->x0.reserve(3));
+    // (a registered array, icm_pin_host, is copied by DMA without staging: 0.054 against 0.078 ms for S2's 2.4 MB; a layout
+    // kernel reading the host array itself over PCIe took 0.09)
     HIPCHK(h, h->x_rows.reserve(3 * T));
     HIPCHK(h, hipMemcpyAsync(h->x_rows.p, x, 3 * T * sizeof(double), hipMemcpyHostToDevice, h->stream));
     k_x_rows_to_poses<<<(int)((T + 255) / 256), 256, 0, h->stream>>>(h->x_rows.p, h->x, (int)T);
+    h->mirror_host = nullptr;
+    std::memcpy(h->h_x0, x0, sizeof(h->h_x0));
     HIPCHK(h, hipMemcpyAsync(h->x0.p, x0, 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipGetLastError());
     // The driver loop hands back the map the previous sweep returned (mapa_viejo = copy(mapa_refinado),
@@ -720,6 +806,8 @@ int icm_set_state(icm_handle* h, const double* x, const double* x0, const double
 // results: what the neighbours need as OLD values (the rank above: the two poses around its ghost solve; the rank
 // below: the pose after its last odd pose).  One message, one collective per sweep.
 constexpr int kStatsHeader = 16;
+constexpr int kStalePoses = 1001;   // internal (icm_sweep_finish -> icm_sweep): the sweep ran from device poses that were not the caller's; nothing was replaced
+constexpr int kStaleWord = 20;      // of the host's mapped block: the epoch of the call whose pose check failed
 int64_t icm_stats_stride(const icm_handle* h) { return h ? 3 * h->cfg.L + kStatsHeader : 0; }
 
 int icm_bind_exchange(icm_handle* h, void* stats_all_dev, int rank, int world) {
@@ -754,6 +842,7 @@ int icm_bind_pose_buffer(icm_handle* h, void* x_dev) {
     if (!h) return ICM_ERR_ARG;
     if (!x_dev) FAIL(h, ICM_ERR_ARG, "icm_bind_pose_buffer: null buffer");
     h->x = reinterpret_cast<double*>(x_dev);
+    h->mirror_host = nullptr;
     h->x_external = true;
     h->rot_valid = false;
     return ICM_OK;
@@ -836,6 +925,10 @@ static FiltrarArgs filtrar_args(icm_handle* h) {
     fa.mapx = h->mapx.p; fa.mapy = h->mapy.p; fa.counts_new = h->counts_new.p;
     fa.gpar = h->gpar.p; fa.g_cell = h->g_cell.p; fa.g_lm = h->g_lm.p; fa.info = h->fl_info.p;
     fa.info_host = nullptr;
+    if (h->x_check) {
+        fa.stale = h->x_stale.p;
+        fa.stale_epoch = h->x_epoch;
+    }
     return fa;
 }
 
@@ -857,6 +950,7 @@ static int launch_filtrar(icm_handle* h, hipStream_t fs, bool guarded = false, i
     FiltrarArgs fa = filtrar_args(h);
     if (guarded) fa.sweep_flags = h->fl;   // queued without a host look at the sweep's flags: the kernels look themselves
     fa.info_host = info_host;              // (a sweep: the outcome goes straight into the host's mapped block)
+    fa.host_map = (info_host && h->host_map_wanted) ? h->pin_map_dev : nullptr;
     const int nb = std::min(kFlMaxBlocks, (L + kFB - 1) / kFB);
     const int chunk = ((L + nb - 1) / nb + kFB - 1) / kFB * kFB;
     TIMED(h, KID_FILTRAR, (k_fl_count<<<nb, kFB, 0, fs>>>(fa, chunk)));
@@ -1234,6 +1328,7 @@ static SolveArgs solve_args(icm_handle* h) {
     a.odo_cs = h->odo_cs.p;
     a.cs = h->pose_cs.p;
     a.epoch = 0;
+    a.xh = nullptr;   // (launch_fused_solve: the one launch whose even waves mirror the poses into the caller's array)
     a.ghost_n = h->ghost_n;
     a.ghost_m = h->gh_m.p;
     return a;
@@ -1243,7 +1338,12 @@ static SolveArgs solve_args(icm_handle* h) {
 // its block plus the ghost pose in front (SolveSeg: t0 = t_begin - 2).
 static SolveSeg shard_segment(const icm_handle* h, const int* abort) {
     const bool ghost = h->world > 1 && h->rank > 0;
-    return SolveSeg{ghost ? (int)h->t_begin - 2 : (int)h->t_begin, (int)(h->t_begin + h->nloc), 0, abort};
+    SolveSeg g{ghost ? (int)h->t_begin - 2 : (int)h->t_begin, (int)(h->t_begin + h->nloc), 0, abort};
+    if (h->x_check) {
+        g.stale = h->x_stale.p;
+        g.stale_epoch = h->x_epoch;
+    }
+    return g;
 }
 
 // Both colours of the poses [g.t0, g.t1) in ONE launch (k_solve_m_fused; lane form), on stream st.  Nothing is queued
@@ -1262,6 +1362,8 @@ static int launch_fused_solve(icm_handle* h, SolveArgs a, SolveSeg g, hipStream_
         h->solve_epoch = 0;
     }
     a.epoch = ++h->solve_epoch;   // (flags and stamps hold the epoch of the launch that set them: no reset between launches)
+    a.xh = h->x_mirror;
+    if (h->x_mirror) h->x_mirrored = true;
     int* const deferred = h->solve_flags.p + h->solve_flag_waves;
     int* const sync = h->solve_flags.p + 2 * (size_t)h->solve_flag_waves;
     // Fold-only Nelder-Mead loop (thirteen coefficients per pose) whenever the folded form can hold at all, i.e. with
@@ -1288,10 +1390,16 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: no state");
     if (h->scan0_empty) return ICM_OK;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->x_check_wait) {    // the check of the caller's poses against the device's (k_x_compare, side stream): done long ago
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_cmp, 0));
+        h->x_check_wait = false;
+    }
     if (h->ghost_pending) {   // the ghost pose's moments (launch_ghost, solve stream)
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gh1, 0));
         h->ghost_pending = false;
     }
+    h->mirror_host = nullptr;   // (poses about to change on the device; icm_sweep says when the caller's array has them too)
+    h->x_mirrored = false;
     SolveArgs a = solve_args(h);
     if (h->debug) {
         const bool fresh = h->diag.cap < 3 * (size_t)h->T;
@@ -1369,6 +1477,10 @@ int icm_sweep_finish(icm_handle* h) {
     if (!h->map_copy_pending) FAIL(h, ICM_ERR_ARG, "icm_sweep_finish: call icm_sweep_targets first");
     HIPCHK(h, hipEventSynchronize(h->ev_copied));  // the solves may still be running
     h->map_copy_pending = false;
+    if (h->x_check && h->pin_i[kStaleWord] == h->x_epoch) {   // (k_x_compare ran on the side stream in front of everything waited for above)
+        h->scan_wanted = true;
+        return kStalePoses;
+    }
     if (h->optimistic) {   // phase A's counts and flags, read only now (the copy was queued behind k_lm_l3)
         if (h->scan_ran) h->E = h->pin_i[0];   // (a sweep without the scan kernels does not count its entries)
         h->n_new_loc = h->pin_i[1];
@@ -1413,6 +1525,14 @@ int icm_sweep_finish(icm_handle* h) {
         h->K = h->lact = h->pin_i[8];
         h->dev_map_current = true;
         h->h_map_valid = false;   // fetched when asked for (sync_host_map)
+        if (h->host_map_wanted && h->filtrar_path == 0) {   // ... or already here: k_fl_finalize wrote it into the host's block
+            const size_t K = (size_t)h->K;
+            h->h_map.resize(2 * K);
+            std::copy(h->pin_map, h->pin_map + K, h->h_map.begin());
+            std::copy(h->pin_map + L, h->pin_map + L + K, h->h_map.begin() + K);
+            h->h_counts.assign(h->pin_map + 2 * L, h->pin_map + 3 * L);
+            h->h_map_valid = true;
+        }
         // No wait for the solves here: everything the host needs (raw map, filtrar result) came
         // over the side stream, and whatever is queued next on the main stream is ordered behind
         // them -- the next sweep's phase A starts the moment the last solve ends.  (Readers of x
@@ -1498,6 +1618,7 @@ int icm_restore_state(icm_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;   // stream-ordered behind the last sweep: no synchronisation needed
     HIPCHK(h, hipMemcpyAsync(h->x, sn.x.p, 3 * T * sizeof(double), hipMemcpyDeviceToDevice, st));
+    h->mirror_host = nullptr;
     h->rot_valid = false;
     h->scan_wanted = true;
     HIPCHK(h, hipMemcpyAsync(h->mapx.p, sn.mapx.p, L * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1522,6 +1643,7 @@ static int icm_sweep_classic(icm_handle* h, int schedule) {
         if (!rc) rc = icm_sweep_solve(h, schedule, -1);
         if (!rc) rc = icm_sweep_finish(h);
         if (rc != ICM_RETRY_CAREFUL) break;
+        if (h->x_check && h->pin_i[kStaleWord] == h->x_epoch) { rc = kStalePoses; break; }   // (the flags mean nothing then)
         // a per-pose or per-chunk table overflowed: solves and Mapa.filtrar saw the flags and changed nothing;
         // once more with the host looking in the middle (it sizes the tables / takes the sort-based pipeline)
     }
@@ -1720,10 +1842,17 @@ int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out,
     }
     const size_t T = (size_t)h->T, L = (size_t)h->cfg.L;
     if (x) {
-        HIPCHK(h, h->x_rows.reserve(3 * T));
-        k_x_poses_to_rows<<<(int)((T + 255) / 256), 256, 0, h->stream>>>(h->x, h->x_rows.p, (int)T);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(x, h->x_rows.p, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (h->mirror_host == x && pinned_alias(h, x, 3 * T * sizeof(double))) {
+            // the solves of the last sweep wrote every pose into this very array themselves (SolveArgs::xh)
+        } else if (double* xa = pinned_alias(h, x, 3 * T * sizeof(double))) {   // a registered array: written in place by the layout kernel
+            k_x_poses_to_rows<<<(int)((T + 255) / 256), 256, 0, h->stream>>>(h->x, xa, (int)T);
+            HIPCHK(h, hipGetLastError());
+        } else {
+            HIPCHK(h, h->x_rows.reserve(3 * T));
+            k_x_poses_to_rows<<<(int)((T + 255) / 256), 256, 0, h->stream>>>(h->x, h->x_rows.p, (int)T);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(x, h->x_rows.p, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     if (map_out) {
@@ -1738,16 +1867,73 @@ int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out,
     return ICM_OK;
 }
 
+// One sweep from the device's own poses, which the caller says (and k_x_compare checks, on the side stream under phase
+// A) are what its registered array `xa` holds: no upload.  kStalePoses: they were not; nothing was replaced.
+static int sweep_without_upload(icm_handle* h, const double* xa, const double* x0, int schedule) {
+    const size_t T = (size_t)h->T;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->x_stale.p) {
+        HIPCHK(h, h->x_stale.reserve(1));
+        HIPCHK(h, hipMemset(h->x_stale.p, 0, sizeof(int)));
+        h->pin_i[kStaleWord] = 0;
+        h->x_epoch = 0;
+    }
+    ++h->x_epoch;
+    if (std::memcmp(x0, h->h_x0, sizeof(h->h_x0)) != 0) {
+        std::memcpy(h->h_x0, x0, sizeof(h->h_x0));
+        HIPCHK(h, hipMemcpyAsync(h->x0.p, h->h_x0, sizeof(h->h_x0), hipMemcpyHostToDevice, h->stream));
+    }
+    k_x_compare<<<(int)((T + 255) / 256), 256, 0, h->copy_stream>>>(xa, h->x, (int)T, h->x_stale.p, h->pin_i_dev + kStaleWord, h->x_epoch);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_cmp, h->copy_stream));
+    h->x_check = h->x_check_wait = true;
+    const int rc = icm_sweep_device(h, schedule);
+    h->x_check = h->x_check_wait = false;
+    return rc;
+}
+
 int icm_sweep(icm_handle* h, double* x, const double* x0, const double* map_in, int64_t K, int64_t lact_in,
               int schedule, double* map_out, double* counts_out, int64_t* K_out) {
+    if (!h) return ICM_ERR_ARG;
     int rc;
-    if ((rc = set_state_impl(h, x, x0, map_in, K, lact_in, false))) return rc;
-    if ((rc = icm_sweep_device(h, schedule))) return rc;
+    const size_t T = (size_t)h->T;
+    // A registered pose array (icm_pin_host): the solves mirror every pose they write into it (no download), and if it is
+    // the array the last call filled and the map is the one that call returned -- the reference's driver loop,
+    // scripts/ICM_ROS.py:298-311 -- this call starts from the device's state without an upload.
+    double* const xa = (x && h->prefiltered && h->world == 1) ? pinned_alias(h, x, 3 * T * sizeof(double)) : nullptr;
+    bool fast = xa && h->have_state && h->mirror_host == x && schedule == ICM_SCHEDULE_REDBLACK && x0 && (K == 0 || map_in) &&
+                h->dev_map_current && K == h->K && lact_in == h->lact;
+    if (fast) {
+        if ((rc = sync_host_map(h))) return rc;   // (already on the host: the last call returned it)
+        fast = h->h_map.size() == 2 * (size_t)K && (K == 0 || std::memcmp(map_in, h->h_map.data(), 2 * (size_t)K * sizeof(double)) == 0);
+    }
+    h->x_mirror = h->form == 0 ? xa : nullptr;
+    h->x_mirrored = false;
+    h->host_map_wanted = true;
+    if (fast) ++h->dropin_counts[0];
+    rc = fast ? sweep_without_upload(h, xa, x0, schedule) : kStalePoses;
+    if (fast && rc == kStalePoses) ++h->dropin_counts[1];
+    if (rc == kStalePoses) {   // the usual road: upload, sweep
+        rc = set_state_impl(h, x, x0, map_in, K, lact_in, false);
+        if (!rc) rc = icm_sweep_device(h, schedule);
+    }
+    h->x_mirror = nullptr;
+    h->host_map_wanted = false;
+    if (rc) {
+        h->mirror_host = nullptr;
+        return rc;
+    }
     if (h->scan0_empty) {
         if (K_out) *K_out = -1;
         return ICM_OK;
     }
-    return icm_get_state(h, x, map_out, counts_out, K_out);
+    if (h->x_mirrored) {   // (the solve launch filled it: icm_get_state below only waits for it)
+        h->mirror_host = x;
+        ++h->dropin_counts[2];
+    }
+    rc = icm_get_state(h, x, map_out, counts_out, K_out);
+    if (!rc && xa) h->mirror_host = x;   // host array == device poses, however they got there
+    return rc;
 }
 
 int icm_get_association(icm_handle* h, int32_t* labels, double* target_x, double* target_y) {
@@ -2165,6 +2351,12 @@ int icm_get_fixup_poses(icm_handle* h, int64_t* poses) {
     HIPCHK(h, hipMemcpyAsync(&v, h->solve_counts.p + 1, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *poses = (int64_t)v;
+    return ICM_OK;
+}
+
+int icm_get_dropin_counts(const icm_handle* h, int64_t* out3) {
+    if (!h || !out3) return ICM_ERR_ARG;
+    for (int i = 0; i < 3; ++i) out3[i] = h->dropin_counts[i];
     return ICM_OK;
 }
 

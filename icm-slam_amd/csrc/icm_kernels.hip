@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, con
                                                   int zero_row = 0) {
     __shared__ int key[kT2];
     __shared__ double sx[kT2], sy[kT2], sn[kT2];
-    __shared__ int used;
+    __shared__ int used, full[2];
     const int tid = threadIdx.x, sc = sc_begin + blockIdx.x;
     // this superchunk's row of the dense matrix takes its landmarks' totals at the end; zero_row: clear
     // it first (otherwise the host has cleared the whole matrix, on a side stream under the solves)
@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, con
         sy[s] = 0.0;
         sn[s] = 0.0;
     }
-    if (tid == 0) used = 0;
+    if (tid == 0) used = full[0] = full[1] = 0;
     __syncthreads();
     const int c0 = sc * G, c1 = min(c0 + G, nchunks);
     // The records of the next kAhead chunks are in flight while one chunk is folded in.  Loads and
@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, con
             if (lab != kEmpty) {
                 bool inserted;
                 const int slot = table_slot(key, kT2 - 1, 21, lab, inserted);
-                if (inserted) atomicAdd(&used, 1);
+                if (inserted && atomicAdd(&used, 1) >= kT2Cap) full[c & 1] = 1;   // (a chunk adds < 256 landmarks: the 2048 slots cannot run out before the look below)
                 ox = sx[slot];   // a landmark has one record per chunk: no two threads meet in a slot
                 oy = sy[slot];
                 on = sn[slot];
@@ -1617,12 +1617,12 @@ __global__ __launch_bounds__(kT1) void k_chunk_l2(int nchunks, int G, int L, con
             off_x[r] = ox;
             off_y[r] = oy;
             off_n[r] = on;
-            // workgroup barriers that wait for this wave's LDS traffic only: __syncthreads() would
-            // also drain the global loads in flight for the next chunks
+            // ONE workgroup barrier per chunk (round 3 had two, around a look at the fill count: the overflow mark now
+            // alternates between two words, so a thread already in the next chunk cannot change the one being looked at),
+            // and one that waits for this wave's LDS traffic only: __syncthreads() would also drain the global loads in
+            // flight for the next chunks
             lds_barrier();
-            const int u = used;   // read between two barriers: the same value in every thread
-            lds_barrier();
-            if (u > kT2Cap) {
+            if (full[c & 1]) {   // the same value in every thread: more than kT2Cap distinct landmarks in the superchunk
                 overflow = true;
                 break;
             }
@@ -1833,6 +1833,9 @@ struct FiltrarArgs {
     LmRec* g_lm;
     int* info;
     int* info_host = nullptr;   // nullable: the host's mapped copy of info[0..2] (k_fl_finalize writes both)
+    double* host_map = nullptr; // nullable: [x (L) | y (L) | counters (L)] in the host's mapped memory: k_fl_finalize writes the refined map there as well
+    const int* stale = nullptr; // nullable: *stale == stale_epoch = this sweep ran from poses that were not the caller's (SolveSeg::stale)
+    int stale_epoch = 0;
 };
 
 __device__ __forceinline__ int block_exscan_1024(int v, int* wsum, int& total) {
@@ -1949,7 +1952,7 @@ __global__ __launch_bounds__(kFB) void k_fl_count(FiltrarArgs a, int chunk) {
         a.st->part_keep[b] = tot;
         if (b == 0) {
             a.st->close = a.st->same = a.st->host = 0;
-            a.st->abort = a.sweep_flags ? (a.sweep_flags[0] | a.sweep_flags[1] | a.sweep_flags[2]) : 0;
+            a.st->abort = (a.sweep_flags ? (a.sweep_flags[0] | a.sweep_flags[1] | a.sweep_flags[2]) : 0) | ((a.stale && *a.stale == a.stale_epoch) ? 1 : 0);
         }
     }
 }
@@ -2075,13 +2078,19 @@ __global__ __launch_bounds__(kFB) void k_fl_finalize(FiltrarArgs a) {
     // so only the table's coordinates are rewritten.
     const int stride = gridDim.x * kFB, t0 = blockIdx.x * kFB + threadIdx.x;
     for (int i = t0; i < a.L; i += stride) {
+        double mx = 0.0, my = 0.0, c = 0.0;
         if (i < n) {
-            const double c = a.pc[i];
-            a.mapx[i] = (a.px[i] * c) / c;
-            a.mapy[i] = (a.py[i] * c) / c;
-            a.counts_new[i] = c;
-        } else {
-            a.counts_new[i] = 0.0;
+            c = a.pc[i];
+            mx = (a.px[i] * c) / c;
+            my = (a.py[i] * c) / c;
+            a.mapx[i] = mx;
+            a.mapy[i] = my;
+        }
+        a.counts_new[i] = c;
+        if (a.host_map) {   // (the drop-in call: what the caller gets back, without a copy launch behind the chain)
+            a.host_map[i] = mx;
+            a.host_map[(size_t)a.L + i] = my;
+            a.host_map[2 * (size_t)a.L + i] = c;
         }
     }
     for (int p = t0; p < n; p += stride) {
@@ -2246,6 +2255,9 @@ struct SolveArgs {
     const double* odo_cs; // (T,2): (cos, sin) of the odometry headings (k_odo_trig)
     double* cs;           // (T,2): (cos, sin)(theta) of every pose as it stands (k_pose_rot / store_pose_tables / the headers)
     int epoch;            // of the one-launch solve (k_solve_m_fused): its flags and deferral stamps hold the epoch that set them
+    double* xh;           // nullable (k_solve_m_fused only): the caller's own (3,T) pose array, registered host memory
+                          // (icm_pin_host): the even waves write every pose there as well, over PCIe, while the launch's
+                          // chains run -- the drop-in call then needs no download behind the sweep
     // ghost pose of a shard (rank > 0): the lower neighbour's last pose t_begin - 1, solved redundantly so that the
     // shard's first even pose needs nothing from another rank in the middle of the sweep (local index tl = -1)
     int ghost_n;          // its kept beams (0: none)
@@ -2262,6 +2274,20 @@ __device__ __forceinline__ void store_pose_xyz(const SolveArgs& a, int tg, const
         a.x[3 * (size_t)tg] = res[0];
         a.x[3 * (size_t)tg + 1] = res[1];
         a.x[3 * (size_t)tg + 2] = res[2];
+    }
+}
+// The caller's own (3,T) array (registered host memory): an EVEN pose's lane writes the pair (tg - 1, tg) of each row --
+// its odd neighbour is final by then -- so that a wave's stores are whole lines over PCIe (one 8-byte store per pose and
+// row took the solve launch from 0.08 to 0.3 ms); the last pose, when it is odd, goes with its even neighbour too.
+__device__ __forceinline__ void mirror_pose_pair(const SolveArgs& a, int tg, double r0, double r1, double r2) {
+    struct __attribute__((packed, aligned(8))) Pair { double lo, hi; };   // (tg - 1 is odd: 8-byte aligned; one 16-byte store)
+    const double* lo = a.x + 3 * (size_t)(tg - 1);
+    const double r[3] = {r0, r1, r2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double* row = a.xh + (size_t)i * a.T;
+        *reinterpret_cast<Pair*>(row + tg - 1) = Pair{lo[i], r[i]};
+        if (tg + 2 == a.T) row[tg + 1] = lo[6 + i];
     }
 }
 // The pairs kept beside a pose: (cos, sin)(theta - pi/2) for phase A / the moment kernel of the next sweep, (cos, sin)(theta)
@@ -2665,7 +2691,12 @@ __device__ __forceinline__ bool solve_pose_moments(const SolveArgs& a, int tg, c
 struct SolveSeg {
     int t0, t1, shift;
     const int* abort;   // nullable: the sweep's flags; any of [0..2] set = leave the poses alone
+    const int* stale = nullptr;   // nullable: *stale == stale_epoch = the device poses this sweep started from were not the
+    int stale_epoch = 0;          // caller's (k_x_compare, the drop-in call without an upload): leave the poses alone
 };
+__device__ __forceinline__ bool seg_aborted(const SolveSeg& g) {   // (final before the launch began: uniform over the grid)
+    return (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) || (g.stale && *g.stale == g.stale_epoch);
+}
 
 __device__ __forceinline__ int seg_pose(const SolveSeg& g, bool even, int j) {
     return g.t0 + 2 * j + (even ? 2 * (1 - g.shift) : 1);
@@ -2673,7 +2704,7 @@ __device__ __forceinline__ int seg_pose(const SolveSeg& g, bool even, int j) {
 
 // Red-black half sweep over a segment, moment form: one LANE per pose of the colour (64 poses per wave).
 __global__ __launch_bounds__(kBlock) void k_solve_m_colour(SolveArgs a, SolveSeg g, int colour) {
-    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;
+    if (seg_aborted(g)) return;
     const int lane = lane_id();
     const int j = (blockIdx.x * kWavesPerBlock + wave_in_block()) * kWave + lane;
     const int tg = seg_pose(g, colour == 0, j);
@@ -2731,7 +2762,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
     // into a memory system this launch leaves idle, instead of a memset launch (or 15 MB more for one of phase B's
     // bandwidth-bound kernels).  (Not all at once at the head of the launch: 15 MB of stores in front of the odd waves'
     // first loads delayed the whole chain by 4-5 us.)
-    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) {   // (the flags were final before this launch began: uniform over the grid)
+    if (seg_aborted(g)) {
         if (zero_out && gw >= nw)   // (the matrix is cleared whatever becomes of the sweep: the host counts on it)
             for (unsigned q = (unsigned)(gw - nw) * kWave + lane; q < zero_n; q += (unsigned)nw * kWave) zero_out[q] = 0.0;
         return;
@@ -2817,12 +2848,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
             if (redo) {
                 const double res[3] = {r0, r1, r2};
                 store_pose(a, tgc, res, false);
+                if (a.xh) mirror_pose_pair(a, tgc, r0, r1, r2);
             }
         } else {
             // (odd poses are handed to the even waves of this launch: write-through (sc1) stores, no cache-wide release needed)
             if (ready && mine) {
                 const double res[3] = {r0, r1, r2};
                 store_pose_xyz(a, tg, res, !even);
+                if (a.xh && even) mirror_pose_pair(a, tg, r0, r1, r2);
             }
             WAVE_TS(2);
             if (!even) {
@@ -2871,7 +2904,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
 // The same half sweep in latency form: one DPP quad (4 lanes) per pose, 16 poses per wave
 // (nelder_mead3_quad).
 __global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, SolveSeg g, int colour) {
-    if (g.abort && (g.abort[0] | g.abort[1] | g.abort[2])) return;
+    if (seg_aborted(g)) return;
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     const int j = gid >> 2, role = gid & 3;
     const int tg = seg_pose(g, colour == 0, j);

@@ -43,6 +43,8 @@ SIGNATURES = {
     "icm_prefilter": (C.c_int, [_H, _lp]),
     "icm_get_kept": (C.c_int, [_H, _lp, _ip, _dp, _dp, _dp]),
     "icm_sweep": (C.c_int, [_H, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp, _lp]),
+    "icm_pin_host": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
+    "icm_unpin_host": (C.c_int, [_H, C.c_void_p]),
     "icm_set_state": (C.c_int, [_H, _dp, _dp, _dp, C.c_int64, C.c_int64]),
     "icm_sweep_device": (C.c_int, [_H, C.c_int]),
     "icm_get_state": (C.c_int, [_H, _dp, _dp, _dp, _lp]),
@@ -94,6 +96,7 @@ SIGNATURES = {
     "icm_set_fold_mode": (C.c_int, [_H, C.c_int]),
     "icm_set_assoc_persistence": (C.c_int, [_H, C.c_int]),
     "icm_get_fixup_poses": (C.c_int, [_H, _lp]),
+    "icm_get_dropin_counts": (C.c_int, [_H, _lp]),
     "icm_staging_layout": (C.c_int, [C.c_int64, C.c_int64, _lp]),
     "icm_set_fused_spin_limit": (C.c_int, [_H, C.c_int]),
     "icm_get_fused_deferred": (C.c_int, [_H, _lp]),

@@ -167,11 +167,13 @@ class SweepEngine:
         self.T = self.B = self.nloc = 0
         self.t_begin = 0
         self.nnz = 0
+        self._last_x = self._pinned_x = None   # _pin_if_reused
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.icm_destroy(self.h)
+            self.lib.icm_destroy(self.h)   # (unregisters whatever icm_pin_host registered)
             self.h = None
+        self._last_x = self._pinned_x = None
 
     def __del__(self):
         try:
@@ -266,14 +268,31 @@ class SweepEngine:
         mv = _f64(mapa_viejo)
         K = mv.shape[1]
         x0v = _f64(np.asarray(x0, dtype=np.float64).reshape(3))
-        mo = np.zeros((2, self.L))
-        co = np.zeros(self.L)
+        mo = np.empty((2, self.L))     # (the library writes every element: zero padded like Mapa.filtrar's return)
+        co = np.empty(self.L)
         ko = C.c_int64(0)
+        self._pin_if_reused(x)
         self._chk(self.lib.icm_sweep(self.h, dptr(x), dptr(x0v), dptr(mv), K, int(lact), SCHEDULES[schedule],
                                      dptr(mo), dptr(co), C.byref(ko)))
         if ko.value < 0:
             return None
         return mo, co, int(ko.value)
+
+    def _pin_if_reused(self, x):
+        """The reference's driver loop hands the SAME pose array back sweep after sweep (it is updated in place,
+        scripts/ICM_ROS.py:158,164,298-311).  An array seen in two consecutive calls is registered with the GPU runtime
+        (icm_pin_host): from then on the library reads and writes it in place over PCIe instead of through two staged
+        2.4 MB copies.  The engine keeps a reference to the registered array, so its memory cannot be freed and its
+        address re-used while registered; one array at a time (a new one replaces it)."""
+        if self._pinned_x is x:
+            return
+        if self._last_x is x:       # second call in a row with this very array
+            if self._pinned_x is not None:
+                self.lib.icm_unpin_host(self.h, C.c_void_p(self._pinned_x.ctypes.data))
+                self._pinned_x = None
+            if self.lib.icm_pin_host(self.h, C.c_void_p(x.ctypes.data), C.c_size_t(x.nbytes)) == 0:
+                self._pinned_x = x
+        self._last_x = x
 
     # ---- device-resident sweeps --------------------------------------------------------
     def set_state(self, mapa_viejo, x, x0, lact=None):
@@ -481,6 +500,13 @@ class SweepEngine:
         n = C.c_int64(0)
         self._chk(self.lib.icm_get_fixup_poses(self.h, C.byref(n)))
         return int(n.value)
+
+    def dropin_counts(self):
+        """icm_sweep calls on a registered pose array: (started without an upload, of those: started over because the
+        caller had changed the array, poses written into the caller's array by the solves themselves)."""
+        out = (C.c_int64 * 3)()
+        self._chk(self.lib.icm_get_dropin_counts(self.h, out))
+        return tuple(int(v) for v in out)
 
     def set_fused_spin_limit(self, polls):
         """Polls an even wave of the one-launch solve waits before deferring to the launch's last wave."""

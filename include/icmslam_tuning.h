@@ -64,6 +64,12 @@ int icm_get_fused_deferred(icm_handle *h, int64_t *waves);
 int icm_set_fold_mode(icm_handle *h, int mode);
 int icm_get_fixup_poses(icm_handle *h, int64_t *poses);
 
+/* icm_sweep calls on a registered pose array (icm_pin_host) so far: out3 = [0] calls that started from the device's poses
+ * without an upload (the array was the one the call before filled), [1] of those, calls whose check of the array against
+ * the device failed -- the caller had changed it -- and that started over with an upload, [2] calls whose solves wrote
+ * the poses into the caller's array themselves (no download). */
+int icm_get_dropin_counts(const icm_handle *h, int64_t *out3);
+
 /* Launch form of phase A (k_assoc_group: tras_rot_z + Mapa.actualizar's association and per-scan grouping,
  * scripts/ICM_SLAM_tools.py:168-195), one wavefront per pose in every form:
  *    0  (default) four poses per 256-thread workgroup

@@ -238,3 +238,82 @@ def test_mapa_actualizar_first_scan_branch_and_errors():
     y3 = np.zeros((2, ncl + 1))
     with pytest.raises(IndexError):
         m3.actualizar(y3, y[:, :ncl + 1].copy(), far + 500.0)
+
+
+def test_driver_loop_on_a_registered_pose_array_and_whatever_the_caller_does_to_it():
+    """The drop-in call at resident speed (reference driver loop scripts/ICM_ROS.py:298-311, scripts/example.py:49-52): the
+    pose array the caller hands back sweep after sweep is registered with the GPU runtime from its second sight on, the
+    solves write the poses straight into it (no download) and a call that gets back the array the last call filled
+    starts from the device's poses (no upload), checked against the array on the side.  Whatever the caller does in
+    between -- edits the array in place, swaps in a copy, a reallocated or a non-contiguous array, goes back to the
+    first one, hands in an edited map -- every call must return what a fresh engine returns for the same inputs."""
+    from ICM_ROS import ICM_ROS
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip.synthetic import make_workload
+    wl = make_workload(1900, 100, 180)
+    cfg = ConfigICM(D=dict(wl.config, schedule="redblack"))
+
+    def fresh_call(mapa, x):
+        """the same call on a new object and new arrays: upload, sweep, download -- nothing carried over"""
+        m = ICM_ROS(cfg)
+        m.mediciones, m.odometria, m.u = wl.scans.T.copy(), wl.odometry.copy(), wl.u.copy()
+        m.x0 = wl.x0.reshape(3, 1)
+        m.set_initial_state(x, mapa)
+        mr, xr = m.iterations_process_offline(np.array(mapa), np.array(x))
+        out = mr, xr, m.mapa_obj.cant_obs_i.copy(), m.mapa_obj.landmarks_actuales
+        m._engine.close()
+        return out
+
+    icm = ICM_ROS(cfg)
+    icm.mediciones, icm.odometria, icm.u = wl.scans.T.copy(), wl.odometry.copy(), wl.u.copy()
+    icm.x0 = wl.x0.reshape(3, 1)
+    icm.set_initial_state(wl.x_init, wl.map_init)
+    mapa, x = copy(icm.mapa_viejo), copy(icm.positions)
+    first = x
+    steps = ["same", "same", "same", "edit in place", "same", "copy", "same", "non-contiguous", "first again", "same",
+             "edited map", "same", "same"]
+    for k, what in enumerate(steps):
+        if what == "edit in place":
+            x[0, 700] += 0.05
+            x[2, 1201] -= 0.01
+        elif what == "copy":
+            x = x.copy()
+        elif what == "non-contiguous":
+            big = np.zeros((3, 2 * x.shape[1]))
+            big[:, ::2] = x
+            x = big[:, ::2]
+        elif what == "first again":
+            first[...] = x
+            x = first
+        elif what == "edited map":
+            mapa = mapa.copy()
+            mapa[:, 3] += 0.02
+        want = fresh_call(mapa, x)
+        x_in = x
+        mr, x = icm.iterations_process_offline(mapa, x)
+        assert x is x_in, what
+        assert np.array_equal(mr, want[0]) and np.array_equal(x, want[1]), (k, what)
+        assert np.array_equal(icm.mapa_obj.cant_obs_i, want[2]) and icm.mapa_obj.landmarks_actuales == want[3], (k, what)
+        mapa = copy(mr)
+    n_fast, n_stale, n_mirror = icm._engine.dropin_counts()
+    print("drop-in calls: %d of %d without an upload (%d of them started over: the array had been edited), %d mirrored"
+          % (n_fast, len(steps), n_stale, n_mirror))
+    assert n_fast >= 5 and n_stale == 1 and n_mirror >= 8
+    icm._engine.close()
+
+
+def test_dataset_driver_loop_in_reference_order_with_a_registered_array(icm):
+    """The reference-order (sequential) sweeps of the dataset through a registered array (uploaded by DMA, written in
+    place by the layout kernel): results as in test_driver_loop_reproduces_reference."""
+    init = gold("init_pass.npz")
+    icm.set_initial_state(init["x_init"], init["map_init"], init["cant_obs_i"])
+    mapa_viejo, x = copy(icm.mapa_viejo), copy(icm.positions)
+    for it in range(3):
+        if it == 2:       # third call: back to the state of the first, in the same (by now registered) array
+            x[...] = init["x_init"]
+            mapa_viejo = copy(icm.mapa_viejo)
+            icm.mapa_obj.landmarks_actuales = mapa_viejo.shape[1]
+        mapa_refinado, x = icm.iterations_process_offline(mapa_viejo, x)
+        g = gold("sweep%02d.npz" % (1 if it == 2 else it + 1))
+        assert np.abs(mapa_refinado - g["mapa"]).max() <= 1e-9 and np.abs(x - g["x"]).max() <= 1e-9
+        mapa_viejo = copy(mapa_refinado)
