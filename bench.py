@@ -22,8 +22,9 @@ record `"weak"` of the same JSON line.  `--scaling weak` swaps the two.
 Prints ONE JSON line on rank 0 (contract in the task description) with the extra objects
 `roofline` (dominant kernel, HIP events on the launch stream), `cpu_baseline` (the C oracle on a
 bounded prefix of the same workload, host cores) and, at N = 1, `dropin` (the same sweep through the
-reference's call `ICM_ROS.iterations_process_offline`, host arrays in and out) and `config3`
-(S1 x 20 consecutive sweeps).
+reference's call `ICM_ROS.iterations_process_offline`, host arrays in and out), `config3`
+(S1 x 20 consecutive sweeps) and `dataset` (data_IJAC2018: init pass, one sweep in the reference's order, one red-black
+sweep, beside the survey's timings of the real reference on the same input).
 """
 import argparse
 import json
@@ -462,6 +463,82 @@ def dropin_record(job, steps, warmup):
             "ms_per_step": round(1e3 * el / steps, 4), "value": round((job.T - 1) * steps / el, 1), "unit": "pose-updates/s"}
 
 
+def dataset_record(device):
+    """data_IJAC2018 (BASELINE.json configs[0] / [1]: 1833 poses x 181 beams, config_default.yaml) -- the ONE input the real
+    reference was ever timed on (in the build container; its Python never travels to the GPU box):
+    the initialisation pass (scripts/ICM_ROS.py:102-119 -> icm_init_pass), one sweep in the reference's sequential order and
+    one red-black sweep (scripts/ICM_ROS.py:121-164), each from the state the init pass leaves (fixtures under tests/golden/),
+    resident state, median of five; and the reference's own call (host arrays in and out) in the reference's order."""
+    import torch
+    from copy import deepcopy as copy
+    from ICM_ROS import ICM_ROS
+    from ICM_SLAM_tools import ConfigICM
+    gold = os.path.join(ROOT, "tests", "golden")
+    f_data, f_init = os.path.join(gold, "data_IJAC2018.npz"), os.path.join(gold, "init_pass.npz")
+    if not (os.path.exists(f_data) and os.path.exists(f_init)):
+        return None
+    cfg = ConfigICM("config_default.yaml")
+    icm = ICM_ROS(cfg)
+    icm.device = device
+    icm.load_data(f_data)
+    init = np.load(f_init)
+    x0 = icm.odometria[:, 0]
+    eng = icm._get_engine()
+    T = int(icm.mediciones.shape[1])
+
+    def med(f, n=5):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            f()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    t_init = med(lambda: eng.init_pass(x0), 3)
+    solves_init = int((np.diff(eng.kept_beams()[0])[1:] > 0).sum())
+    out = {"workload": "data_IJAC2018: %d poses x %d beams, config_default.yaml (BASELINE.json configs[0]/[1])" % (T, icm.mediciones.shape[0]),
+           "init_pass": {"ms": round(1e3 * t_init, 3), "solves": solves_init, "solves_per_s": round(solves_init / t_init, 1),
+                         "what": "icm_init_pass incl. the first scan's clustering on the host and all host <-> device copies"}}
+    lact = int(init["landmarks_actuales"])
+    for sched in ("sequential", "redblack"):
+        def one():
+            eng.sweep_device(sched)
+        ts = []
+        for _ in range(5):
+            eng.set_state(init["map_init"], init["x_init"], x0, lact)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[2]
+        out[sched] = {"ms": round(1e3 * t, 4), "pose_updates_per_s": round((T - 1) / t, 1),
+                      "what": "one sweep from (map_init, x_init), state resident in HBM, %s order" % ("the reference's" if sched == "sequential" else "red-black")}
+    icm.set_initial_state(init["x_init"], init["map_init"], init["cant_obs_i"])
+    st = {"m": copy(icm.mapa_viejo), "x": copy(icm.positions)}
+
+    def call():
+        icm.set_initial_state(init["x_init"], init["map_init"], init["cant_obs_i"])
+        st["x"][...] = init["x_init"]
+        icm.iterations_process_offline(st["m"], st["x"])
+    t_call = med(call)
+    out["reference_call"] = {"ms": round(1e3 * t_call, 4), "pose_updates_per_s": round((T - 1) / t_call, 1),
+                             "what": "ICM_ROS.iterations_process_offline(mapa_viejo, x), host arrays in and out, schedule = config_default.yaml's (sequential)"}
+    ref = {"sweep_s": [15.1, 17.5], "pose_updates_per_s": [105, 121], "init_pass_s": [9.3, 11.9], "cores": 1,
+           "provenance": "BASELINE.md section 2: the reference's own Python (imported under a roslibpy stub, ROS-free harness) timed in the "
+                         "build container on ONE core of an 8-core Intel Xeon @ 2.10 GHz, NumPy 2.2.6 / SciPy 1.15.3; not a number "
+                         "published by the reference and not measured on this box"}
+    out["reference_measured"] = ref
+    out["speedup_vs_reference_measured"] = {
+        "sweep_sequential": [round(ref["sweep_s"][0] / (out["sequential"]["ms"] * 1e-3), 0), round(ref["sweep_s"][1] / (out["sequential"]["ms"] * 1e-3), 0)],
+        "sweep_redblack": [round(ref["sweep_s"][0] / (out["redblack"]["ms"] * 1e-3), 0), round(ref["sweep_s"][1] / (out["redblack"]["ms"] * 1e-3), 0)],
+        "init_pass": [round(ref["init_pass_s"][0] / t_init, 0), round(ref["init_pass_s"][1] / t_init, 0)]}
+    eng.close()
+    return out
+
+
 def run_rank(args):
     from icmslam_hip.synthetic import WORKLOADS
     rank = int(os.environ.get("RANK", "0"))
@@ -584,6 +661,13 @@ def run_rank(args):
                           "steps": 20, "warmup": 2, "ms_per_step": round(1e3 * el / 20, 4), "value": round((j3.T - 1) * 20 / el, 1),
                           "unit": "pose-updates/s"}
         j3.close()
+    if rank == 0 and world == 1 and factory is None and not args.no_extras:
+        try:
+            ds = dataset_record(local_rank)
+        except Exception as e:   # (a record beside the headline, never a reason to lose the line)
+            ds = {"error": "%s: %s" % (type(e).__name__, e)}
+        if ds is not None:
+            out["dataset"] = ds
     if rank == 0:
         if json_fd is not None:
             sys.stdout.flush()

@@ -196,6 +196,7 @@ struct icm_handle {
     const double* mirror_host = nullptr;   // the host array whose contents equal the device poses (as far as this library knows)
     DevBuf<int> x_stale;             // [1]: the epoch of the call whose check failed
     int x_epoch = 0;
+    int fault = 0;   // test hook (icm_set_fault): 1 = the next icm_sweep_local reports a HIP error
     int64_t dropin_counts[3] = {0, 0, 0};   // icm_sweep calls: [0] started without an upload, [1] of those: the check failed (started over), [2] poses mirrored into the caller's array
     double h_x0[3] = {0, 0, 0};      // host copy of x0 as uploaded
     bool x_mirrored = false;         // the sweep's solve launch wrote the poses into x_mirror
@@ -282,6 +283,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 } g_rccl;
@@ -305,6 +307,7 @@ bool rccl_load(std::string& err) {
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(lib, "ncclCommAbort"));
     g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(lib, "ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
@@ -998,6 +1001,10 @@ int icm_sweep_local(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_local: no state (icm_set_state)");
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->fault == 1) {
+        h->fault = 0;
+        FAIL(h, ICM_ERR_HIP, "icm_sweep_local: injected fault (icm_set_fault)");
+    }
     h->optimistic = h->opt_req && optimistic_applies(h);
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     // pose 0 without kept beams: the reference returns its inputs untouched
@@ -1201,11 +1208,15 @@ int icm_mark_failed(icm_handle* h, int code) {
     return ICM_OK;
 }
 
-// After the exchange, careful form: the first rank whose header carries an error code (-1: none), and that code.
-int icm_failed_rank(icm_handle* h, int* rank_out, int* code_out) {
+// After the exchange: what the ranks' headers say.  *rank_out / *code_out: the first rank whose header carries an error
+// code (-1 / 0: none); *retry_out (nullable): some rank's tables overflowed in a sweep it had queued whole ([1] == 1) --
+// that rank, and every rank whose flags its message was folded into, will repeat the sweep, so a rank that looks here
+// (careful form) must do the same instead of replacing its state.
+int icm_exchange_status(icm_handle* h, int* rank_out, int* code_out, int* retry_out) {
     if (!h || !rank_out || !code_out) return ICM_ERR_ARG;
     *rank_out = -1;
     *code_out = 0;
+    if (retry_out) *retry_out = 0;
     if (h->world <= 1 || !h->stats_all) return ICM_OK;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t stride = (size_t)icm_stats_stride(h), L = (size_t)h->cfg.L;
@@ -1213,14 +1224,17 @@ int icm_failed_rank(icm_handle* h, int* rank_out, int* code_out) {
     for (int r = 0; r < h->world; ++r)
         HIPCHK(h, hipMemcpyAsync(&hd[(size_t)r], h->stats_all + (size_t)r * stride + 3 * L + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int r = 0; r < h->world; ++r)
-        if (hd[(size_t)r] >= 2.0) {
+    for (int r = 0; r < h->world; ++r) {
+        if (hd[(size_t)r] >= 2.0 && *rank_out < 0) {
             *rank_out = r;
             *code_out = 1 - (int)hd[(size_t)r];
-            break;
         }
+        if (hd[(size_t)r] == 1.0 && retry_out) *retry_out = 1;
+    }
     return ICM_OK;
 }
+
+int icm_failed_rank(icm_handle* h, int* rank_out, int* code_out) { return icm_exchange_status(h, rank_out, code_out, nullptr); }
 
 // After the (optional) all-gather: offsets, raw map, targets.
 int icm_sweep_targets(icm_handle* h) {
@@ -1663,6 +1677,8 @@ int icm_set_optimistic(icm_handle* h, int on) {
     return ICM_OK;
 }
 
+int icm_get_optimistic(const icm_handle* h) { return h ? (h->optimistic ? 1 : 0) : ICM_ERR_ARG; }
+
 // ---- RCCL from inside the library: collectives (the loader is above icm_destroy) ----------------
 #define RCCLCHK(h, call)                                                                                     \
     do {                                                                                                     \
@@ -1782,6 +1798,12 @@ static int all_gather(icm_handle* h, const double* send, double* recv, size_t co
 // + the ghost pose's moments -> both colours of the shard in one launch -> Mapa.filtrar (replicated).
 static int sweep_sharded_once(icm_handle* h);
 
+static const char* phase_a_error_text(int code) {
+    return code == ICM_ERR_INDEX ? "IndexError: labels beyond L or a no-beam last pose"
+         : code == ICM_ERR_CAPACITY ? "a scan touched more distinct landmarks than supported"
+         : code == ICM_ERR_HIP ? "a HIP runtime error" : code == ICM_ERR_ARG ? "a bad argument / call order" : "error";
+}
+
 int icm_sweep_sharded(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->comm_ready) FAIL(h, ICM_ERR_ARG, "icm_sweep_sharded: no communicator (icm_comm_init)");
@@ -1793,30 +1815,59 @@ int icm_sweep_sharded(icm_handle* h) {
         h->opt_req = attempt == 0;
         rc = sweep_sharded_once(h);
         if (rc != ICM_RETRY_CAREFUL) break;
+        if (attempt == 0) {
+            // Before the second collective: a rank that FAILED in the first one has left with its error and will not
+            // join a second (its code, >= 2 in header [1], reads as "flags set" to the ranks that queued the sweep whole):
+            // every rank looks at the headers still in its exchange buffer and leaves with that error too.
+            int fr = -1, code = 0, rc2;
+            if ((rc2 = icm_exchange_status(h, &fr, &code, nullptr))) { rc = rc2; break; }
+            if (fr >= 0) {
+                h->opt_req = req;
+                FAIL(h, code, "sharded sweep: rank " + std::to_string(fr) + " failed in phase A (" + phase_a_error_text(code) + ")");
+            }
+        }
     }
     h->opt_req = req;
     return rc;
 }
 
+// A rank that cannot take part in the exchange at all (its device or stream is gone): tear the communicator down, so that
+// the peers' collective returns with an error instead of waiting for this rank for ever.  (A caller-supplied transport,
+// icm_comm_init_transport, is the caller's to tear down: the error return is all this library can do there.)
+static void comm_abort(icm_handle* h) {
+    if (h->comm && g_rccl.CommAbort) {
+        (void)g_rccl.CommAbort(h->comm);
+        h->comm = nullptr;
+        h->comm_ready = false;
+    }
+}
+
 static int sweep_sharded_once(icm_handle* h) {
     const size_t stride = (size_t)icm_stats_stride(h);
-    // A rank that fails on its own in phase A (careful form: a table too small even at its largest size, labels beyond L,
-    // a no-beam last pose) must not leave the others waiting in the collective: it still sends its message, with the
-    // error code in the header, and every rank returns that error after the exchange.
+    // Failing together.  A rank that fails on its own in phase A -- a property of its data (labels beyond L, a no-beam
+    // last pose, a table too small at its largest size) or of its device (a HIP error) -- must not leave the others
+    // waiting in the collective: it still sends its message, with the error code in the header, and every rank returns
+    // that error after the exchange.
     const int rc_local = icm_sweep_local(h);
-    if (rc_local == ICM_ERR_HIP || rc_local == ICM_ERR_ARG) return rc_local;   // (not a property of the data: nothing sensible to exchange)
-    const std::string err_local = h->err;
     int rc;
-    if (rc_local && (rc = icm_mark_failed(h, rc_local))) return rc;
+    if (rc_local) {
+        const std::string err_local = h->err;
+        rc = icm_mark_failed(h, rc_local);
+        if (!rc) rc = all_gather(h, h->own_stats_send.p, h->own_stats_all.p, stride);
+        if (rc) comm_abort(h);   // (could not even say so)
+        h->err = err_local;
+        return rc_local;
+    }
     rc = all_gather(h, h->own_stats_send.p, h->own_stats_all.p, stride);
     if (rc) return rc;
-    if (!h->optimistic || rc_local) {
-        // careful form: the host looks at every rank's header ([1] >= 2: that rank failed with code 1 - [1])
-        int fr = -1, code = 0;
-        if ((rc = icm_failed_rank(h, &fr, &code))) return rc;
-        if (rc_local) { h->err = err_local; return rc_local; }
+    if (!h->optimistic) {
+        // careful form: the host looks at every rank's header.  [1] >= 2: that rank failed with code 1 - [1]; [1] == 1: a
+        // rank that had queued the sweep whole overflowed -- it and its like will repeat the sweep, and so must this one
+        int fr = -1, code = 0, retry = 0;
+        if ((rc = icm_exchange_status(h, &fr, &code, &retry))) return rc;
         if (fr >= 0)
-            FAIL(h, code, "sharded sweep: rank " + std::to_string(fr) + " failed in phase A (" + (code == ICM_ERR_INDEX ? "IndexError: labels beyond L or a no-beam last pose" : code == ICM_ERR_CAPACITY ? "a scan touched more distinct landmarks than supported" : "error") + ")");
+            FAIL(h, code, "sharded sweep: rank " + std::to_string(fr) + " failed in phase A (" + phase_a_error_text(code) + ")");
+        if (retry) return ICM_RETRY_CAREFUL;
     }
     if ((rc = icm_sweep_targets(h))) return rc;
     if ((rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, -1))) return rc;
@@ -2357,6 +2408,13 @@ int icm_get_fixup_poses(icm_handle* h, int64_t* poses) {
 int icm_get_dropin_counts(const icm_handle* h, int64_t* out3) {
     if (!h || !out3) return ICM_ERR_ARG;
     for (int i = 0; i < 3; ++i) out3[i] = h->dropin_counts[i];
+    return ICM_OK;
+}
+
+int icm_set_fault(icm_handle* h, int where) {
+    if (!h) return ICM_ERR_ARG;
+    if (where < 0 || where > 1) FAIL(h, ICM_ERR_ARG, "icm_set_fault: 0 (none) or 1 (the next icm_sweep_local reports a HIP error)");
+    h->fault = where;
     return ICM_OK;
 }
 

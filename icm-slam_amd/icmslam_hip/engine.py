@@ -322,6 +322,22 @@ class SweepEngine:
         self._chk(self.lib.icm_failed_rank(self.h, C.byref(r), C.byref(c)))
         return int(r.value), int(c.value)
 
+    def exchange_status(self):
+        """After the exchange: (rank, code, retry) -- the first rank that failed in phase A with its code (-1, 0: none) and
+        whether some rank reports flags of a sweep it had queued whole, i.e. everybody repeats the sweep
+        (icm_exchange_status)."""
+        r, c, q = C.c_int(-1), C.c_int(0), C.c_int(0)
+        self._chk(self.lib.icm_exchange_status(self.h, C.byref(r), C.byref(c), C.byref(q)))
+        return int(r.value), int(c.value), bool(q.value)
+
+    def sweep_is_optimistic(self):
+        """Whether the sweep sweep_local() started was queued whole (a request, set_optimistic, is not always granted)."""
+        return self.lib.icm_get_optimistic(self.h) == 1
+
+    def set_fault(self, where):
+        """Test hook: 1 = the next sweep_local fails like a HIP error (icm_set_fault)."""
+        self._chk(self.lib.icm_set_fault(self.h, int(where)))
+
     def sweep_solve(self, schedule="redblack", colour=-1):
         self._chk(self.lib.icm_sweep_solve(self.h, SCHEDULES[schedule], int(colour)))
 

@@ -93,28 +93,44 @@ class ShardedSweep:
         for attempt in (0, 1):
             if can:
                 e.set_optimistic(attempt == 0)
-            # a rank whose phase A fails on its own (careful form: labels beyond L, a table too small at its largest
-            # size) still sends its message, with the error code in the header: every rank fails together
+            # Failing together: a rank whose phase A fails on its own (labels beyond L, a no-beam last pose, a table too
+            # small at its largest size, a device error) still sends its message, with the error code in the header, and
+            # every rank raises after the exchange.
             err = None
             try:
                 e.sweep_local()
-            except (IndexError, RuntimeError) as ex:
+            except (IndexError, RuntimeError, ValueError) as ex:
                 if not hasattr(e, "mark_failed") or getattr(e, "last_rc", 0) >= 0:
                     raise
                 err = ex
                 e.mark_failed(e.last_rc)
             self.comm.gather_stats(self)            # the sweep's one collective
-            if hasattr(e, "failed_rank") and (err is not None or attempt == 1 or not can):
-                fr, code = e.failed_rank()
+            status = getattr(e, "exchange_status", None)
+            whole = can and attempt == 0 and err is None and (e.sweep_is_optimistic() if hasattr(e, "sweep_is_optimistic") else True)
+            if status is not None and not whole:
+                # this rank's sweep was not queued whole: it looks at every header now.  A rank that reports flags of a
+                # sweep IT had queued whole will repeat the sweep with everybody of its kind -- so must this one.
+                fr, code, retry = status()
                 if err is not None:
                     raise err
                 if fr >= 0:
                     from .engine import _raise
                     _raise(code, "sharded sweep: rank %d failed in phase A" % fr)
+                if retry and attempt == 0:
+                    continue
+            elif err is not None:
+                raise err
             e.sweep_targets()
             e.sweep_solve("redblack", -1)           # both colours, ghost pose included, one launch
             if not e.sweep_finish():
                 break
+            if status is not None:
+                # before the repeated sweep's collective: a rank that FAILED in this one has left with its error and will
+                # not join another (its code reads as "flags set" to the ranks that queued the sweep whole)
+                fr, code, _ = status()
+                if fr >= 0:
+                    from .engine import _raise
+                    _raise(code, "sharded sweep: rank %d failed in phase A" % fr)
         if can:
             e.set_optimistic(False)
 

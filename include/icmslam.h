@@ -183,6 +183,7 @@ int icm_gather_poses(icm_handle *h);
  * ICM_RETRY_CAREFUL if something overflowed.  Red-black sweeps through the default pipeline only; else the request is
  * ignored for that sweep. */
 int icm_set_optimistic(icm_handle *h, int on);
+int icm_get_optimistic(const icm_handle *h);          /* 1: the sweep icm_sweep_local started WAS queued whole */
 int icm_sweep_local(icm_handle *h);                   /* phase A + local statistics          */
 int icm_sweep_targets(icm_handle *h);                 /* prefix over ranks -> targets, map   */
 int icm_sweep_solve(icm_handle *h, int schedule, int colour); /* colour 1 = odd, 0 = even,  */
@@ -195,6 +196,14 @@ int icm_sweep_finish(icm_handle *h);                  /* Mapa.filtrar, next mapa
  * *code_out its ICM_ERR_* code).  icm_sweep_sharded does both itself. */
 int icm_mark_failed(icm_handle *h, int code);
 int icm_failed_rank(icm_handle *h, int *rank_out, int *code_out);
+/* The same look at every rank's header, plus *retry_out = 1 when some rank reports flags of a sweep it had queued whole
+ * (header [1] == 1): that rank and every rank that queued the sweep whole will repeat it (ICM_RETRY_CAREFUL from their
+ * icm_sweep_finish), so a rank whose own sweep was NOT queued whole (icm_get_optimistic() == 0 after icm_sweep_local) must
+ * call this after the exchange and, on retry, skip icm_sweep_targets / _solve / _finish and repeat the sweep with them.
+ * And before ANY rank starts the repeated sweep's exchange it calls this once more: a rank that failed in the first
+ * exchange (code in its header) has left and will not join a second one -- every rank then stops with that code.
+ * icm_sweep_sharded does all of it. */
+int icm_exchange_status(icm_handle *h, int *rank_out, int *code_out, int *retry_out);
 
 /* ---- kernel-level entry points for parity tests ---------------------------------------- */
 /* Labels of every kept beam after phase A of the last sweep (reference `c` of

@@ -70,6 +70,10 @@ int icm_get_fixup_poses(icm_handle *h, int64_t *poses);
  * the poses into the caller's array themselves (no download). */
 int icm_get_dropin_counts(const icm_handle *h, int64_t *out3);
 
+/* Test hook: where = 1 makes the next icm_sweep_local fail with ICM_ERR_HIP before it launches anything (a rank of a
+ * sharded job whose device failed: it must still take part in the sweep's collective, icm_sweep_sharded); 0 = off. */
+int icm_set_fault(icm_handle *h, int where);
+
 /* Launch form of phase A (k_assoc_group: tras_rot_z + Mapa.actualizar's association and per-scan grouping,
  * scripts/ICM_SLAM_tools.py:168-195), one wavefront per pose in every form:
  *    0  (default) four poses per 256-thread workgroup

@@ -2,6 +2,8 @@
 (the collective becomes shared memory), against the unsharded sweep; the RCCL all-gather path itself
 with a 1-rank process group; three OS processes with the messages carried over gloo -- through the
 torch.distributed driver and through the C library's own driver (icm_comm_init_transport)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -337,3 +339,230 @@ def test_a_rank_local_failure_is_collective(tmp_path):
     res = [open(out % r).read() for r in range(world)]
     print(res)
     assert all(r.startswith("IndexError") for r in res), res
+
+
+def _protocol_worker(rank, world, port, out_path, driver, case):
+    """One rank of a three-process job in which ONE rank cannot finish phase A of the sweep's FIRST attempt (the one
+    every rank queues whole): case "hip" -- rank 1's device reports an error (icm_set_fault); case "nobeam" -- the
+    sequence's last pose has no kept beams (the reference's IndexError, scripts/ICM_ROS.py:144: a property of the data
+    that only the owner of the last block sees).  Every rank must come back with the error; nobody may wait in a second
+    collective for a rank that has left."""
+    import ctypes
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "icm-slam_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import LibrarySweep, ShardedSweep, TorchComm, partition
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from util import hip_runtime
+
+    class HostHopComm(TorchComm):
+        def _ag(self, out, inp):
+            o, i = out.cpu(), inp.cpu()
+            self.dist.all_gather_into_tensor(o, i, group=self.group)
+            out.copy_(o)
+
+        def gather_stats(self, sw):
+            self._ag(sw.stats, sw.stats_send)
+
+        def all_gather(self, buf, r, count):
+            self._ag(buf, buf[r * count:(r + 1) * count].clone())
+
+    calls = []
+
+    def gloo_transport(send_ptr, recv_ptr, count, stream_ptr):
+        hip = hip_runtime()
+        assert hip.hipStreamSynchronize(ctypes.c_void_p(stream_ptr)) == 0
+        mine = torch.empty(count, dtype=torch.float64)
+        allr = torch.empty(count * world, dtype=torch.float64)
+        assert hip.hipMemcpy(ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(send_ptr), ctypes.c_size_t(8 * count), 2) == 0
+        dist.all_gather_into_tensor(allr, mine)
+        assert hip.hipMemcpy(ctypes.c_void_p(recv_ptr), ctypes.c_void_p(allr.data_ptr()), ctypes.c_size_t(8 * count * world), 1) == 0
+        calls.append(count)
+
+    wl, cfg = _workload()
+    scans = wl.scans
+    _, parts = partition(wl.T, world)
+    a, b = parts[rank]
+    e = SweepEngine(cfg)
+    e.upload(scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=scans[a - 1] if a else None)
+    run = LibrarySweep(e, rank, world, wl.T, transport=gloo_transport) if driver == "library" else ShardedSweep(e, rank, world, wl.T, comm=HostHopComm())
+    run.set_state(wl.map_init, wl.x_init, wl.x0)
+    run.sweep("redblack")             # a clean sweep first: the job is in its steady state (sweeps queued whole)
+    if case == "hip" and rank == 1:
+        e.set_fault(1)
+    outcome = "ok"
+    try:
+        run.sweep("redblack")
+    except (IndexError, RuntimeError) as ex:
+        outcome = "%s: %s" % (type(ex).__name__, ex)
+    open(out_path % rank, "w").write(outcome + "\ncollectives=%d" % len(calls))
+    e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("driver,case,port", [("library", "hip", 29601), ("torch", "hip", 29611), ("library", "nobeam", 29621), ("torch", "nobeam", 29631)])
+def test_a_rank_that_fails_in_a_sweep_queued_whole_takes_every_rank_with_it(tmp_path, driver, case, port):
+    """The first attempt of a sharded sweep is queued whole on every rank.  A rank that fails in it on its own -- a
+    device error, or the no-beam last pose only the last block's owner sees -- sends its message with the error code
+    and leaves; its peers, to whom the code reads as "flags set: repeat the sweep", must find the code in the headers
+    BEFORE they start the repeated sweep's collective, and leave with the same error (round 3 hung here)."""
+    import torch.multiprocessing as mp
+    world = 3
+    out = str(tmp_path / "rank%d.txt")
+    mp.spawn(_protocol_worker_entry, args=(world, port, out, driver, case), nprocs=world, join=True)
+    res = [open(out % r).read() for r in range(world)]
+    print(driver, case, res)
+    want = "IcmError: icmslam_hip error -2" if case == "hip" else "IndexError"      # (IcmError is a RuntimeError)
+    assert all(r.startswith(want) for r in res), res
+
+
+def _protocol_worker_entry(rank, world, port, out_path, driver, case):
+    if case == "nobeam":
+        _nobeam_worker(rank, world, port, out_path, driver)
+    else:
+        _protocol_worker(rank, world, port, out_path, driver, case)
+
+
+def _nobeam_worker(rank, world, port, out_path, driver):
+    """case "nobeam" of _protocol_worker without the clean sweep in front (the last pose never has beams)."""
+    import ctypes
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "icm-slam_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import LibrarySweep, ShardedSweep, TorchComm, partition
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from util import hip_runtime
+
+    class HostHopComm(TorchComm):
+        def _ag(self, out, inp):
+            o, i = out.cpu(), inp.cpu()
+            self.dist.all_gather_into_tensor(o, i, group=self.group)
+            out.copy_(o)
+
+        def gather_stats(self, sw):
+            self._ag(sw.stats, sw.stats_send)
+
+        def all_gather(self, buf, r, count):
+            self._ag(buf, buf[r * count:(r + 1) * count].clone())
+
+    def gloo_transport(send_ptr, recv_ptr, count, stream_ptr):
+        hip = hip_runtime()
+        assert hip.hipStreamSynchronize(ctypes.c_void_p(stream_ptr)) == 0
+        mine = torch.empty(count, dtype=torch.float64)
+        allr = torch.empty(count * world, dtype=torch.float64)
+        assert hip.hipMemcpy(ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(send_ptr), ctypes.c_size_t(8 * count), 2) == 0
+        dist.all_gather_into_tensor(allr, mine)
+        assert hip.hipMemcpy(ctypes.c_void_p(recv_ptr), ctypes.c_void_p(allr.data_ptr()), ctypes.c_size_t(8 * count * world), 1) == 0
+
+    wl, cfg = _workload()
+    scans = wl.scans.copy()
+    scans[-1, :] = 1e3                # beyond rango_laser_max: filtrar_z keeps nothing of the last scan
+    _, parts = partition(wl.T, world)
+    a, b = parts[rank]
+    e = SweepEngine(cfg)
+    e.upload(scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=scans[a - 1] if a else None)
+    run = LibrarySweep(e, rank, world, wl.T, transport=gloo_transport) if driver == "library" else ShardedSweep(e, rank, world, wl.T, comm=HostHopComm())
+    run.set_state(wl.map_init, wl.x_init, wl.x0)
+    outcome = "ok"
+    try:
+        run.sweep("redblack")
+    except (IndexError, RuntimeError) as ex:
+        outcome = "%s: %s" % (type(ex).__name__, ex)
+    open(out_path % rank, "w").write(outcome)
+    e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _s2_worker(rank, world, port, out_path):
+    """One of `world` OS processes, each holding one block of the full S2 sequence on cuda:0: icm_sweep_sharded (sweeps
+    queued whole) with its collective carried over gloo."""
+    import ctypes
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "icm-slam_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import LibrarySweep, partition
+    from icmslam_hip.synthetic import WORKLOADS, make_workload
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from util import hip_runtime
+    calls = []
+
+    def gloo_transport(send_ptr, recv_ptr, count, stream_ptr):
+        hip = hip_runtime()
+        assert hip.hipStreamSynchronize(ctypes.c_void_p(stream_ptr)) == 0
+        mine = torch.empty(count, dtype=torch.float64)
+        allr = torch.empty(count * world, dtype=torch.float64)
+        assert hip.hipMemcpy(ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(send_ptr), ctypes.c_size_t(8 * count), 2) == 0
+        dist.all_gather_into_tensor(allr, mine)
+        assert hip.hipMemcpy(ctypes.c_void_p(recv_ptr), ctypes.c_void_p(allr.data_ptr()), ctypes.c_size_t(8 * count * world), 1) == 0
+        calls.append(count)
+
+    wl = make_workload(*WORKLOADS["S2"])
+    cfg = ConfigICM(D=wl.config)
+    _, parts = partition(wl.T, world)
+    a, b = parts[rank]
+    e = SweepEngine(cfg)
+    e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.scans[a - 1] if a else None)
+    del wl.scans
+    run = LibrarySweep(e, rank, world, wl.T, transport=gloo_transport)
+    run.set_state(wl.map_init, wl.x_init, wl.x0)
+    states = []
+    for _ in range(2):
+        run.sweep("redblack")
+        # (the pose blocks travel with get_state: a collective of its own, outside the sweep)
+        n0 = len(calls)
+        states.append(run.get_state())
+        del calls[n0:]
+    assert calls == [e.stats_stride()] * 2, "one collective per sweep: %r" % (calls,)
+    (x1, m1, c1, K1), (x2, m2, c2, K2) = states
+    np.savez(out_path % rank, x1=x1, m1=m1[:, :K1], c1=c1, K1=K1, x2=x2, m2=m2[:, :K2], c2=c2, K2=K2, path=e.entry_path(), deferred=e.fused_deferred())
+    e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_full_s2_in_four_processes_through_the_library_driver(tmp_path):
+    """BASELINE configs[4]'s job -- the full 100 000-pose sequence, pose-sharded -- as FOUR OS processes on the one GPU
+    (the box allows six), each driving icm_sweep_sharded on its 25 000-pose block with every sweep queued whole and the
+    collective carried between the processes over gloo: poses, map and counters after sweeps 1 and 2 against the C
+    oracle's full-size fixture, replicas bit-equal."""
+    import torch.multiprocessing as mp
+    from util import GOLD
+    world = 4
+    out = str(tmp_path / "s2rank%d.npz")
+    mp.spawn(_s2_worker, args=(world, 29651, out), nprocs=world, join=True)
+    fx = np.load(os.path.join(GOLD, "s2_fullsize.npz"))
+    res = [np.load(out % r) for r in range(world)]
+    for r, g in enumerate(res):
+        assert str(g["path"]) == "hier"
+        for s in ("1", "2"):
+            K = int(g["K" + s])
+            d = np.abs(g["x" + s] - fx["x" + s]).max(axis=0)
+            if r == 0:
+                print("S2 in %d processes vs C oracle after sweep %s: K %d/%d  max|dmap| %.2e  max|dx| %.3e  poses above 1e-9: %d"
+                      % (world, s, K, int(fx["K" + s]), np.abs(g["m" + s] - fx["map" + s]).max(), d.max(), int((d > 1e-9).sum())))
+            assert K == int(fx["K" + s]) and np.abs(g["m" + s] - fx["map" + s]).max() <= 1e-9 and d.max() <= 1e-9
+            cs = g["c" + s]
+            assert np.array_equal(cs[:fx["counts" + s].size], fx["counts" + s]) and not cs[fx["counts" + s].size:].any()
+    for g in res[1:]:
+        assert np.array_equal(g["x2"], res[0]["x2"]) and np.array_equal(g["m2"], res[0]["m2"])
