@@ -272,6 +272,24 @@ class Job:
             out.append(self.window(steps))
         return out
 
+    def phase_report(self, sweeps=3):
+        """After the timed windows of a sharded job: a few more sweeps with events at the phase boundaries
+        (icm_set_phase_timing), one line per rank on stderr -- local phase A / the exchange including the wait for the
+        slowest rank / targets, ghost pose and moments / the solve launch / host wait at the end -- so that a scaling
+        record can be read: which phase, on which rank, is the sweep waiting for."""
+        if not self.sharded or not hasattr(self.eng, "set_phase_timing"):
+            return
+        self.fence()
+        self.eng.set_phase_timing(True)
+        for _ in range(sweeps):
+            self.step()
+        self.fence()
+        ph, n = self.eng.phase_times()
+        self.eng.set_phase_timing(False)
+        sys.stderr.write("bench.py phases (ms per sweep, %d diagnostic sweeps) rank %d/%d poses [%d, %d): %s\n"
+                         % (n, self.rank, self.world, self.t_begin, self.t_end, json.dumps(ph)))
+        sys.stderr.flush()
+
     def close(self):
         if hasattr(getattr(self, "runner", None), "close"):
             self.runner.close()
@@ -604,6 +622,10 @@ def run_rank(args):
                   (" -- ONE sequence of %d x %d poses, a %d-pose block per GPU" % (world, T1, job.blk) if mode == "weak"
                    else " -- the %d-pose sequence split into %d-pose blocks (BASELINE.json configs[4])" % (T, job.blk)))}
         records[mode] = rec
+        try:
+            job.phase_report()
+        except Exception as e:      # (diagnostics only)
+            sys.stderr.write("bench.py: phase report failed on rank %d: %s\n" % (rank, e))
         if mode == args.scaling:
             main_job, main_ms = job, ms
         else:

@@ -8,6 +8,7 @@
 // (icm_sweep_sharded: RCCL resolved with dlopen, or the caller's all-gather) or by the caller between the phase calls.
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include <dlfcn.h>
 
@@ -196,6 +197,11 @@ struct icm_handle {
     const double* mirror_host = nullptr;   // the host array whose contents equal the device poses (as far as this library knows)
     DevBuf<int> x_stale;             // [1]: the epoch of the call whose check failed
     int x_epoch = 0;
+    // icm_set_phase_timing: events on the handle's stream at the phase boundaries of a (sharded) sweep
+    bool phase_timing = false;
+    hipEvent_t ev_ph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double ph_ms[5] = {0, 0, 0, 0, 0};   // local | exchange (+ waiting for the slowest rank) | targets | solve | host time in finish
+    int64_t ph_n = 0;
     int fault = 0;   // test hook (icm_set_fault): 1 = the next icm_sweep_local reports a HIP error
     int64_t dropin_counts[3] = {0, 0, 0};   // icm_sweep calls: [0] started without an upload, [1] of those: the check failed (started over), [2] poses mirrored into the caller's array
     double h_x0[3] = {0, 0, 0};      // host copy of x0 as uploaded
@@ -262,6 +268,11 @@ struct icm_handle {
         }                                                                      \
     } while (0)
 
+static inline double host_now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
 static inline int nblocks_waves(int64_t nwaves) { return (int)((nwaves + kWavesPerBlock - 1) / kWavesPerBlock); }
 static inline int nblocks_threads(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
@@ -419,6 +430,7 @@ int icm_destroy(icm_handle* h) {
     h->gh_ranges.release(); h->gh_bd.release(); h->gh_bx.release(); h->gh_by.release(); h->gh_bxy.release(); h->gh_kmask.release(); h->kmask.release(); h->gh_s2.release(); h->gh_sx.release(); h->gh_sy.release();
     h->gh_rot.release(); h->gh_m.release(); h->gh_nkept.release(); h->gh_boff.release(); h->gh_bk.release(); h->gh_label.release(); h->gh_bloc.release();
     h->gh_st_label.release(); h->gh_misc.release(); h->gh_st_k.release();
+    for (auto& e : h->ev_ph) if (e) (void)hipEventDestroy(e);
     if (h->ev_cmp) (void)hipEventDestroy(h->ev_cmp);
     h->x_stale.release();
     if (h->ev_gh0) (void)hipEventDestroy(h->ev_gh0);
@@ -1007,6 +1019,7 @@ int icm_sweep_local(icm_handle* h) {
     }
     h->optimistic = h->opt_req && optimistic_applies(h);
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
+    if (h->phase_timing) (void)hipEventRecord(h->ev_ph[0], h->stream);
     // pose 0 without kept beams: the reference returns its inputs untouched
     // (scripts/ICM_ROS.py:133-135).  Every rank sees the same scan 0 only if it owns it; the
     // host side checks this before sharding.
@@ -1131,6 +1144,7 @@ int icm_sweep_local(icm_handle* h) {
         if (h->world > 1)
             k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), L, 0.0, 0.0, h->x, edge_first(h), edge_last(h), edge_last2(h), run_scan ? h->new_rank.p + nloc : h->fl + 9, h->fl);
         HIPCHK(h, hipGetLastError());
+        if (h->phase_timing) (void)hipEventRecord(h->ev_ph[1], h->stream);
         return ICM_OK;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1242,6 +1256,7 @@ int icm_sweep_targets(icm_handle* h) {
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_targets: no state");
     if (h->scan0_empty) return ICM_OK;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->phase_timing && h->optimistic) (void)hipEventRecord(h->ev_ph[2], h->stream);   // (behind the exchange, which is ordered on this stream)
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     const int nlab = h->lact0 + (int)h->n_new_loc;
     const bool ghost = h->world > 1 && h->rank > 0;
@@ -1414,6 +1429,8 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     }
     h->mirror_host = nullptr;   // (poses about to change on the device; icm_sweep says when the caller's array has them too)
     h->x_mirrored = false;
+    const bool ph = h->phase_timing && h->optimistic;
+    if (ph) (void)hipEventRecord(h->ev_ph[3], h->stream);
     SolveArgs a = solve_args(h);
     if (h->debug) {
         const bool fresh = h->diag.cap < 3 * (size_t)h->T;
@@ -1464,6 +1481,7 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         FAIL(h, ICM_ERR_ARG, "icm_sweep_solve: unknown schedule");
     }
     HIPCHK(h, hipGetLastError());
+    if (ph) (void)hipEventRecord(h->ev_ph[4], h->stream);
     return ICM_OK;
 }
 
@@ -1489,8 +1507,19 @@ int icm_sweep_finish(icm_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     const size_t L = (size_t)h->cfg.L;
     if (!h->map_copy_pending) FAIL(h, ICM_ERR_ARG, "icm_sweep_finish: call icm_sweep_targets first");
+    const double t_fin0 = h->phase_timing ? host_now_ms() : 0.0;
     HIPCHK(h, hipEventSynchronize(h->ev_copied));  // the solves may still be running
     h->map_copy_pending = false;
+    if (h->phase_timing && h->optimistic) {   // (diagnostic sweeps only: this wait for the solves is not part of a normal sweep)
+        h->ph_ms[4] += host_now_ms() - t_fin0;
+        if (hipEventSynchronize(h->ev_ph[4]) == hipSuccess) {
+            for (int i = 0; i < 4; ++i) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, h->ev_ph[i], h->ev_ph[i + 1]) == hipSuccess) h->ph_ms[i] += ms;
+            }
+            ++h->ph_n;
+        }
+    }
     if (h->x_check && h->pin_i[kStaleWord] == h->x_epoch) {   // (k_x_compare ran on the side stream in front of everything waited for above)
         h->scan_wanted = true;
         return kStalePoses;
@@ -2408,6 +2437,25 @@ int icm_get_fixup_poses(icm_handle* h, int64_t* poses) {
 int icm_get_dropin_counts(const icm_handle* h, int64_t* out3) {
     if (!h || !out3) return ICM_ERR_ARG;
     for (int i = 0; i < 3; ++i) out3[i] = h->dropin_counts[i];
+    return ICM_OK;
+}
+
+int icm_set_phase_timing(icm_handle* h, int on) {
+    if (!h) return ICM_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (on)
+        for (auto& e : h->ev_ph)
+            if (!e) HIPCHK(h, hipEventCreate(&e));
+    h->phase_timing = on != 0;
+    for (double& v : h->ph_ms) v = 0.0;
+    h->ph_n = 0;
+    return ICM_OK;
+}
+
+int icm_get_phase_times(const icm_handle* h, double* out5, int64_t* sweeps) {
+    if (!h || !out5 || !sweeps) return ICM_ERR_ARG;
+    for (int i = 0; i < 5; ++i) out5[i] = h->ph_ms[i];
+    *sweeps = h->ph_n;
     return ICM_OK;
 }
 

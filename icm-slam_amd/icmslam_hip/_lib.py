@@ -73,6 +73,8 @@ SIGNATURES = {
     "icm_exchange_status": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "icm_get_optimistic": (C.c_int, [_H]),
     "icm_set_fault": (C.c_int, [_H, C.c_int]),
+    "icm_set_phase_timing": (C.c_int, [_H, C.c_int]),
+    "icm_get_phase_times": (C.c_int, [_H, _dp, _lp]),
     "icm_get_association": (C.c_int, [_H, _ip, _dp, _dp]),
     "icm_get_raw_map": (C.c_int, [_H, _dp, _dp, _lp]),
     "icm_solve_one": (C.c_int, [_H, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _dp]),

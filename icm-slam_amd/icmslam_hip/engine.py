@@ -334,6 +334,19 @@ class SweepEngine:
         """Whether the sweep sweep_local() started was queued whole (a request, set_optimistic, is not always granted)."""
         return self.lib.icm_get_optimistic(self.h) == 1
 
+    def set_phase_timing(self, on=True):
+        """Events at the phase boundaries of every sweep queued whole (diagnostics of a sharded job: icm_set_phase_timing)."""
+        self._chk(self.lib.icm_set_phase_timing(self.h, 1 if on else 0))
+
+    def phase_times(self):
+        """ms per sweep of {local, exchange (+ waiting for the slowest rank), targets, solve, finish (host wait)} since
+        set_phase_timing, and the number of sweeps."""
+        out = np.zeros(5)
+        n = C.c_int64(0)
+        self._chk(self.lib.icm_get_phase_times(self.h, dptr(out), C.byref(n)))
+        k = max(int(n.value), 1)
+        return dict(zip(("local", "exchange", "targets", "solve", "finish_host_wait"), (out / k).round(4).tolist())), int(n.value)
+
     def set_fault(self, where):
         """Test hook: 1 = the next sweep_local fails like a HIP error (icm_set_fault)."""
         self._chk(self.lib.icm_set_fault(self.h, int(where)))

@@ -70,6 +70,14 @@ int icm_get_fixup_poses(icm_handle *h, int64_t *poses);
  * the poses into the caller's array themselves (no download). */
 int icm_get_dropin_counts(const icm_handle *h, int64_t *out3);
 
+/* Diagnostics of a sharded job (bench.py prints them per rank at N > 1): with phase timing on, every sweep queued whole
+ * records HIP events on the handle's stream at its phase boundaries and icm_sweep_finish waits for the solves (so the
+ * sweeps are a few microseconds slower and no longer overlap: never inside a timed window).  icm_get_phase_times:
+ * accumulated ms over *sweeps sweeps: [0] phase A + local statistics, [1] the exchange including the wait for the
+ * slowest rank, [2] targets / ghost pose / moments, [3] the solve launch, [4] host time spent waiting in icm_sweep_finish. */
+int icm_set_phase_timing(icm_handle *h, int on);
+int icm_get_phase_times(const icm_handle *h, double *out5, int64_t *sweeps);
+
 /* Test hook: where = 1 makes the next icm_sweep_local fail with ICM_ERR_HIP before it launches anything (a rank of a
  * sharded job whose device failed: it must still take part in the sweep's collective, icm_sweep_sharded); 0 = off. */
 int icm_set_fault(icm_handle *h, int where);

@@ -247,6 +247,14 @@ def _native_worker(rank, world, port, out_path, driver):
         assert calls == [e.stats_stride()] * sweeps, "exactly one collective per sweep: %r" % (calls,)
     x, m, c, K = run.get_state()
     np.savez(out_path % rank, x=x, m=m[:, :K], c=c, K=K, path=e.entry_path())
+    # the per-rank phase report bench.py prints at N > 1 (icm_set_phase_timing): two more sweeps with events at the phase boundaries
+    e.set_phase_timing(True)
+    for _ in range(2):
+        run.sweep("redblack")
+    ph, n = e.phase_times()
+    e.set_phase_timing(False)
+    print("rank %d phases (ms per sweep): %s" % (rank, ph))
+    assert n == 2 and all(v >= 0.0 for v in ph.values()) and ph["local"] > 0.0 and ph["solve"] > 0.0
     e.close()
     dist.barrier()
     dist.destroy_process_group()
