@@ -1752,6 +1752,9 @@ int64_t icm_shard_block(int64_t T, int world) {
 static int comm_setup(icm_handle* h, int rank, int world) {
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t blk = icm_shard_block(h->T, world);
+    if (world > 1 && (int64_t)(world - 1) * blk >= h->T)
+        FAIL(h, ICM_ERR_ARG, "icm_comm_init: " + std::to_string(h->T) + " poses cannot be split into " + std::to_string(world) + " blocks of " + std::to_string(blk) +
+                             " (every shard starts at an even pose and holds at least one pose): use fewer ranks");
     if (h->t_begin != std::min<int64_t>((int64_t)rank * blk, h->T) || h->t_begin + h->nloc != std::min<int64_t>((int64_t)(rank + 1) * blk, h->T))
         FAIL(h, ICM_ERR_ARG, "icm_comm_init: the uploaded shard is not block `rank` of icm_shard_block(T, world)-pose blocks");
     const size_t stride = (size_t)icm_stats_stride(h);

@@ -2512,7 +2512,10 @@ __global__ __launch_bounds__(kWave) void k_ghost_moments(const double* __restric
     for (int q = 0; q < kMomentCount; ++q) m[q] = 0.0;
     double mxx = 0.0, mxy = 0.0, myy = 0.0;
     bool bad = false;
-    for (int q = lane; q < n; q += kWave) {
+    // (the owner's order of additions, k_pose_moments_h: sixteen lanes stride over the entries, then a DPP row sum -- the other
+    // 48 lanes idle; what still differs from the owner is the last bits of the TARGETS, whose running sums the two ranks add
+    // up in different associations)
+    for (int q = lane; q < n && lane < 16; q += 16) {
         const int lab = st_label[j0 + q];
         const double k = (double)st_k[j0 + q], sbx = st_sbx[j0 + q], sby = st_sby[j0 + q];
         double sx, sy, sn;
@@ -2536,10 +2539,10 @@ __global__ __launch_bounds__(kWave) void k_ghost_moments(const double* __restric
         myy += sby * sby / k;
     }
 #pragma unroll
-    for (int q = 0; q < kMomentCount; ++q) m[q] = wave_sum(m[q]);
-    mxx = wave_sum(mxx);
-    mxy = wave_sum(mxy);
-    myy = wave_sum(myy);
+    for (int q = 0; q < kMomentCount; ++q) m[q] = row_sum16(m[q]);
+    mxx = row_sum16(mxx);
+    mxy = row_sum16(mxy);
+    myy = row_sum16(myy);
     if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < kMomentCount; ++q) gm[q] = m[q];

@@ -18,8 +18,9 @@ Per sweep (the loop being sharded is scripts/ICM_ROS.py:14
   4. both colours of the shard in ONE launch.  A red-black sweep solves the odd poses from old even
      neighbours, then the even poses from new odd neighbours; shards start at even poses, so the only
      value a shard would need from another rank in mid-sweep is the new value of the odd pose in front
-     of it -- and that one it computes itself, from the same beams, targets and neighbour values as
-     its owner (the ghost pose).  No halo exchange.
+     of it -- and that one it computes itself (the ghost pose), from the same beams and neighbour values
+     as its owner and from targets that equal the owner's up to the rounding of differently associated
+     sums (~1e-16 relative: include/icmslam.h, icm_upload_ghost_scan).  No halo exchange.
   5. Mapa.filtrar, replicated (deterministic) on every rank
 
 The pose blocks themselves are gathered only when the caller asks for the state (`get_state`), not
@@ -35,8 +36,26 @@ def shard_block(T, world):
     return blk + (blk & 1)
 
 
+def world_fits(T, world):
+    """Every one of `world` even-sized blocks holds at least one pose."""
+    return world == 1 or (world - 1) * shard_block(T, world) < T
+
+
+def usable_world(T, world):
+    """The largest world size <= `world` that world_fits (not every smaller one does: T = 21 splits 6 or 11 ways, not 7..10)."""
+    while world > 1 and not world_fits(T, world):
+        world -= 1
+    return world
+
+
 def partition(T, world):
+    """(block, [(a_r, b_r)]) -- blocks of shard_block(T, world) poses.  Rounding the block up to an even number can leave
+    trailing ranks without poses (T = 21, world = 7: blocks of 4 cover the sequence with six ranks): refused here, with
+    the largest usable world size, rather than failing later in icm_upload."""
     blk = shard_block(T, world)
+    if not world_fits(T, world):
+        raise ValueError("a %d-pose sequence cannot be split into %d blocks of %d poses (every shard starts at an even pose "
+                         "and holds at least one): use %d ranks" % (T, world, blk, usable_world(T, world)))
     return blk, [(min(r * blk, T), min((r + 1) * blk, T)) for r in range(world)]
 
 

@@ -76,9 +76,13 @@ int icm_upload(icm_handle *h, const double *ranges, const double *odo, const dou
                const double *cosb, const double *sinb, int64_t T, int64_t B, int64_t t_begin,
                int64_t t_end);
 /* Multi-rank jobs, ranks > 0 only (between icm_upload and icm_prefilter): the scan of pose t_begin - 1, the last pose
- * of the shard below.  A shard solves that pose as well (its "ghost pose": same beams, same targets, same
- * neighbours' values as its owner uses), so that the shard's first even pose finds its odd neighbour without an exchange
- * between the two colours of a sweep (reference loop scripts/ICM_ROS.py:141-158; a pose reads t-1 and t+1 only, :211-214).
+ * of the shard below.  A shard solves that pose as well (its "ghost pose": the same beams, the same neighbours' values
+ * and the same additions over its entries as its owner uses; its TARGETS -- the running means through that pose -- are
+ * the same numbers up to the rounding of sums the two ranks add up in different associations, ~1e-16 relative), so that
+ * the shard's first even pose finds its odd neighbour without an exchange between the two colours of a sweep (reference
+ * loop scripts/ICM_ROS.py:141-158; a pose reads t-1 and t+1 only, :211-214).  A Nelder-Mead result is a simplex vertex,
+ * so the ghost's result is its owner's bit for bit unless one of the solve's comparisons flips on those last bits; the
+ * owner's value replaces it with the next exchange either way (tests: equal on every pose tested, bounded by 1e-9).
  *   ranges_row [B] */
 int icm_upload_ghost_scan(icm_handle *h, const double *ranges_row);
 /* filtrar_z for every scan of the shard, once per sequence (reference

@@ -574,3 +574,54 @@ def test_full_s2_in_four_processes_through_the_library_driver(tmp_path):
             assert np.array_equal(cs[:fx["counts" + s].size], fx["counts" + s]) and not cs[fx["counts" + s].size:].any()
     for g in res[1:]:
         assert np.array_equal(g["x2"], res[0]["x2"]) and np.array_equal(g["m2"], res[0]["m2"])
+
+
+def test_a_ghost_pose_is_solved_to_its_owners_value():
+    """A shard solves the pose in front of it too (its ghost pose) instead of receiving it between the colours: same
+    beams, same neighbours' values, the same additions over its entries as its owner -- and targets that are the same
+    running means up to the rounding of differently associated sums.  Directly: after one sweep, before any rank's
+    block reaches the others, rank r's own copy of pose a_r - 1 against rank r - 1's."""
+    import torch
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import NoComm, ShardedSweep, partition
+    wl, cfg = _workload()
+    world = 4
+    _, parts = partition(wl.T, world)
+    engines, runs, stats = [], [], None
+    for r, (a, b) in enumerate(parts):
+        e = SweepEngine(cfg)
+        e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.scans[a - 1] if a else None)
+        run = ShardedSweep(e, r, world, wl.T, comm=NoComm(), stats=stats)
+        stats = run.stats
+        run.set_state(wl.map_init, wl.x_init, wl.x0)
+        engines.append(e)
+        runs.append(run)
+    for sweep in range(2):
+        for e in engines:
+            e.sweep_local()
+        torch.cuda.synchronize()
+        for e in engines:
+            e.sweep_targets()
+        for e in engines:
+            e.sweep_solve("redblack", -1)
+        for e in engines:
+            e.sweep_finish()
+        torch.cuda.synchronize()
+        worst, equal = 0.0, 0
+        for r in range(1, world):
+            a = parts[r][0]
+            ghost = runs[r].poses.view(-1, 3)[a - 1].cpu().numpy()
+            owner = runs[r - 1].poses.view(-1, 3)[a - 1].cpu().numpy()
+            worst = max(worst, float(np.abs(ghost - owner).max()))
+            equal += int(np.array_equal(ghost, owner))
+            assert not np.array_equal(owner, wl.x_init[:, a - 1]), "the pose was solved"
+        print("sweep %d: ghost poses bit-equal to their owners' %d of %d, max |difference| %.2e" % (sweep + 1, equal, world - 1, worst))
+        assert worst <= 1e-9
+        n = runs[0].blk * 3          # the pose blocks reach the other ranks (get_state's all-gather)
+        for src in runs:
+            for dst in runs:
+                if dst is not src:
+                    dst.poses[src.rank * n:(src.rank + 1) * n].copy_(src.poses[src.rank * n:(src.rank + 1) * n])
+        torch.cuda.synchronize()
+    for e in engines:
+        e.close()

@@ -66,3 +66,24 @@ def test_ranks_gloo_match_unsharded_oracle(tmp_path, world):
         assert np.array_equal(r["c"], st.cant_obs_i)
     for r1 in res[1:]:
         assert np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["m"], r1["m"])   # replicas agree
+
+
+def test_partition_refuses_world_sizes_that_leave_a_rank_without_poses():
+    """Blocks are rounded up to an even number of poses, so some (T, world) pairs that divide cleanly leave trailing ranks
+    empty (T = 21, world = 7: blocks of 4 cover the sequence with six ranks): refused up front, naming the next smaller usable
+    world size; every accepted partition covers the sequence with non-empty blocks that start at even poses."""
+    import pytest
+    from icmslam_hip.sharded import partition, world_fits
+    with pytest.raises(ValueError, match="use 6 ranks"):
+        partition(21, 7)
+    with pytest.raises(ValueError, match="use 3 ranks"):
+        partition(10, 4)
+    for T in (5, 10, 21, 600, 1833, 100000):
+        for world in range(1, 12):
+            if not world_fits(T, world):
+                with pytest.raises(ValueError):
+                    partition(T, world)
+                continue
+            blk, parts = partition(T, world)
+            assert parts[0][0] == 0 and parts[-1][1] == T and all(b > a and a % 2 == 0 for a, b in parts)
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
