@@ -358,11 +358,18 @@ def choose_collectives(args, rank, world, local_rank, dist):
 
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json), and the file it was
-    made from; (None, None) without one.  Only for a one-GPU run of the full workload (that is what was profiled)."""
+    made from; (None, reason) without one -- or when the summary was made with ANOTHER build of the library than the one
+    loaded (the file is stamped with icm_build_id(): counter traffic of kernels that have changed since says nothing).
+    Only for a one-GPU run of the full workload (that is what was profiled)."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        return int(tj[workload][kernel]), tj.get("_source", {}).get(workload)
-    except (OSError, KeyError, ValueError, TypeError):
+        val, src = int(tj[workload][kernel]), tj.get("_source", {}).get(workload)
+        from icmslam_hip import _lib
+        have, want = _lib.load().icm_build_id().decode(), (tj.get("_build_id") or {}).get(workload)
+        if want != have:
+            return None, "stale: %s was profiled on build %s, this is build %s" % (src, want, have)
+        return val, src
+    except (OSError, KeyError, ValueError, TypeError, AttributeError):
         return None, None
 
 

@@ -26,6 +26,11 @@
 #include "../../include/icmslam_tuning.h"
 #include "icm_host.hpp"
 #include "eval_flops.h"
+#if __has_include("build_id.h")
+#include "build_id.h"   // written by the Makefile: sha256 of the sources
+#else
+#define ICM_BUILD_ID "unknown"
+#endif
 #include "icm_kernels.hip"
 
 using namespace icm;
@@ -145,8 +150,6 @@ struct icm_handle {
     int fl_parity = 0;        //   and k_lm_l3 clears the other half for the next sweep (no memset launch at a sweep's head)
     bool fl_next_clean = false;
     int cu_count = 256;       // compute units of the device (icm_create)
-    int assoc_wave_wgs = 0;   // phase A: four poses per 256-thread workgroup (0, default) or one-wave workgroups (1): measured equal
-    int assoc_wg_per_cu = 0;  // phase A on persistent waves: workgroups per CU; 0 (default): one short-lived wave per pose
     int fold_mode = -1;       // -1 automatic (fold-only main kernel + fix-up when the weights are isotropic), 0 never, 1 always
     // ghost pose of a shard (rank > 0): scan, kept beams, staged entries and moments of pose t_begin - 1
     bool ghost_uploaded = false;
@@ -278,7 +281,8 @@ static inline int nblocks_threads(int64_t n) { return (int)((n + kBlock - 1) / k
 
 extern "C" {
 
-const char* icm_version(void) { return "icmslam-hip 0.3 (gfx950)"; }
+const char* icm_version(void) { return "icmslam-hip 0.4 (gfx950)"; }
+const char* icm_build_id(void) { return ICM_BUILD_ID; }
 
 int icm_flop_per_eval(void) { return ICM_FLOP_PER_EVAL; }
 int icm_valu_per_eval(void) { return ICM_VALU_PER_EVAL; }
@@ -396,8 +400,6 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
         }
         h->thr2 = s2;
     }
-    if (const char* ev = std::getenv("ICM_ASSOC_WAVE_WGS")) h->assoc_wave_wgs = std::atoi(ev) != 0;
-    if (const char* ev = std::getenv("ICM_ASSOC_PERSIST")) h->assoc_wg_per_cu = std::max(0, std::min(16, std::atoi(ev)));   // (profiling runs)
     h->own_stream = true;
     h->h_counts.assign((size_t)cfg->L, 0.0);
     *out = h;
@@ -1038,21 +1040,9 @@ int icm_sweep_local(icm_handle* h) {
     GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p};
     const bool dbg = h->debug || h->per_beam;
     h->assoc_kept = dbg;
-    // Production form (no pre-set labels, no per-beam dump): PERSISTENT waves, as many workgroups as the chip holds at
-    // once (assoc_wg_per_cu per CU: 8 with the 128-slot table, half of that with the 256-slot one), each wave striding
-    // over the poses with the next pose's header and first beams in flight.  assoc_wg_per_cu == 0: one pose per wave.
 #define ASSOC_ARGS h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bxy.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
         h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->fl, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->stl.sparse0
-#define ASSOC_GROUP(PRE, DBG, HS)                                                                                  \
-    do {                                                                                                           \
-        const int wgs__ = h->assoc_wg_per_cu * h->cu_count / (HS == 128 ? 1 : 2);                                  \
-        if (!(PRE) && !(DBG) && wgs__ > 0)                                                                         \
-            TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<false, false, HS, 0><<<std::min(nblocks_waves(nloc), wgs__), kBlock, 0, h->stream>>>(ASSOC_ARGS))); \
-        else if (!(PRE) && !(DBG) && h->assoc_wave_wgs)   /* one wave = one workgroup = one pose */                  \
-            TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<false, false, HS, 1, 1><<<nloc, kWave, 0, h->stream>>>(ASSOC_ARGS))); \
-        else                                                                                                       \
-            TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS, 1><<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(ASSOC_ARGS))); \
-    } while (0)
+#define ASSOC_GROUP(PRE, DBG, HS) TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS><<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(ASSOC_ARGS)))
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
     if (!h->rot_valid) {   // (the poses came from the host, a snapshot or a solve form that does not keep the table)
         TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p, h->pose_cs.p)));
@@ -2473,14 +2463,6 @@ int icm_set_fold_mode(icm_handle* h, int mode) {
     if (!h) return ICM_ERR_ARG;
     if (mode < -1 || mode > 1) FAIL(h, ICM_ERR_ARG, "icm_set_fold_mode: mode must be -1, 0 or 1");
     h->fold_mode = mode;
-    return ICM_OK;
-}
-
-int icm_set_assoc_persistence(icm_handle* h, int workgroups_per_cu) {
-    if (!h) return ICM_ERR_ARG;
-    if (workgroups_per_cu < -1 || workgroups_per_cu > 16) FAIL(h, ICM_ERR_ARG, "icm_set_assoc_persistence: -1 .. 16");
-    h->assoc_wave_wgs = workgroups_per_cu == -1;
-    h->assoc_wg_per_cu = std::max(workgroups_per_cu, 0);
     return ICM_OK;
 }
 

@@ -798,15 +798,11 @@ struct PoseTable {
     int owner[HS];
 };
 
-// PPW consecutive poses per wave (1 or more; > 1 only for the plain configuration, with the rotation table): while a
-// pose is grouped, the next pose's header (beam range, pose, rotation -- scalar loads) and its first 64 beams are
-// already in flight, so only the wave's first pose pays the dependent chain beam offsets -> beams -> grid record.
-// WPB = waves per workgroup.  The waves of a workgroup share nothing here, but a workgroup gives its wave slots back
-// only when its LAST wave ends, and scans differ in length (0 .. 720 kept beams): with four poses per workgroup a sixth
-// of the chip's wave-slot time stood empty behind the longest pose of each group (SQ_WAVE_CYCLES: 6.6 of 8 slots
-// filled on average).  One-wave workgroups recycle every slot the moment its pose is done.
-template <bool PRELABEL, bool DEBUG, int HS, int PPW = 1, int WPB = kWavesPerBlock>
-__global__ __launch_bounds__(WPB * kWave) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_ASSOC_WPE : 4, HS == 128 ? 8 : 5)))
+// One wave per pose, four poses per 256-thread workgroup.  (Measured and dropped, DESIGN.md appendix: several consecutive
+// poses per wave with the next pose's header and first beams in flight -- 0.192 / 0.202 / 0.217 ms at 1 / 2 / 4 poses per
+// wave; persistent waves striding over the poses -- +19 % .. +51 %; one-wave workgroups -- no difference.)
+template <bool PRELABEL, bool DEBUG, int HS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_ASSOC_WPE : 4, HS == 128 ? 8 : 5)))
 void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int t_begin, int nloc, const int* __restrict__ boff,
                                                         const double2* __restrict__ bxy,
@@ -818,22 +814,12 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         const double* __restrict__ rot = nullptr, int nnz_total = 0,
                                                         int* __restrict__ st_off = nullptr, const int* __restrict__ plan = nullptr,
                                                         int pose0 = 0, int sparse0 = 0) {
-    static_assert(PPW == 1 || (!PRELABEL && !DEBUG), "several poses per wave: plain configuration only");
-    // PPW == 0: PERSISTENT waves -- the grid holds as many waves as the chip has wave slots and wave w takes the poses w,
-    // w + W, w + 2 W, ...  A wave's life is a chain of dependent round trips (beam offsets -> beams -> grid record -> LDS
-    // grouping), and eight waves per SIMD do not cover it (the vector pipe idles a fifth of the time although it is the
-    // busiest unit); a wave that stays can have the NEXT pose's header and first 64 beams -- and the beam offsets of the
-    // pose after that -- in flight while it groups the current one, so only its first pose pays the start-up chain.
-    // (PPW > 1, consecutive poses per short-lived wave, hid the same latency but paid for it in wave quantisation:
-    // 50 000 waves of two poses on 8 192 slots are seven rounds where 6.1 would do.)
-    constexpr bool PERSIST = PPW == 0;
     constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
     constexpr int kHashShift = HS == 128 ? 25 : 24;
-    __shared__ PoseTable<HS> tables[WPB];
+    __shared__ PoseTable<HS> tables[kWavesPerBlock];
     const int lane = lane_id();
-    const int w0 = __builtin_amdgcn_readfirstlane((blockIdx.x * WPB + wave_in_block()) * (PERSIST ? 1 : PPW));
-    const int stride = PERSIST ? (int)(gridDim.x * WPB) : 1;
-    if (w0 >= nloc) return;
+    const int tl = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave_in_block());
+    if (tl >= nloc) return;
     PoseTable<HS>& T = tables[wave_in_block()];
     const GridParams gp = *g.par;
     // (explicit 32-bit byte offsets from a scalar base: a pose has far fewer than 2^29 beams)
@@ -842,66 +828,16 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     auto beam_at = [](const double2* __restrict__ base, unsigned idx) {
         return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + (idx << 4));
     };
-    // header and first 64 beams of the pose that comes next (at first: of the wave's first pose)
-    int hj0 = __builtin_amdgcn_readfirstlane(boff[w0]), hj1 = __builtin_amdgcn_readfirstlane(boff[w0 + 1]);
-    double hpx, hpy, hth, hct, hst;
-    pose_of(x, x0, t_begin + w0, hpx, hpy, hth);
-    if (rot) {   // (cos, sin)(theta - pi/2) from the sweep's table: the same values, computed once
-        hct = rot[2 * (size_t)w0];
-        hst = rot[2 * (size_t)w0 + 1];
-    } else {
-        pose_rot(hth, hct, hst);
-    }
-    double fbx = 0.0, fby = 0.0;
-    if (hj1 > hj0) {
-        const unsigned i0 = min((unsigned)lane, (unsigned)(hj1 - hj0) - 1u);
-        const double2 f = beam_at(bxy + hj0, i0);
-        fbx = f.x;
-        fby = f.y;
-    }
-    int nj0 = 0, nj1 = 0;   // persistent: beam range of the pose after next (scalar loads, two poses ahead)
-    if (PERSIST && w0 + stride < nloc) {
-        nj0 = __builtin_amdgcn_readfirstlane(boff[w0 + stride]);
-        nj1 = __builtin_amdgcn_readfirstlane(boff[w0 + stride + 1]);
-    }
-#pragma unroll 1
-    for (int pp = 0; PERSIST || pp < PPW; ++pp) {
-    const int tl = w0 + pp * stride;
-    if (tl >= nloc) break;
     // (wave-uniform values through scalar registers: the pose's beam range becomes a scalar base pointer plus a
     // 32-bit lane offset)
-    const int j0 = hj0, j1 = hj1;
-    const double px = hpx, py = hpy, ct = hct, st = hst;
-    double nbx = fbx, nby = fby;
-    if (PERSIST) {
-        const int tn = tl + stride;
-        if (tn < nloc) {   // the next pose's header and first beams, requested now; the beam range of the one after
-            hj0 = nj0;
-            hj1 = nj1;
-            const int t2 = tn + stride;
-            if (t2 < nloc) {
-                nj0 = __builtin_amdgcn_readfirstlane(boff[t2]);
-                nj1 = __builtin_amdgcn_readfirstlane(boff[t2 + 1]);
-            }
-            pose_of(x, x0, t_begin + tn, hpx, hpy, hth);
-            hct = rot[2 * (size_t)tn];
-            hst = rot[2 * (size_t)tn + 1];
-            const unsigned i1 = min((unsigned)lane, (unsigned)max(hj1 - hj0, 1) - 1u);   // (a pose without beams reads one in-range beam nobody uses)
-            const unsigned b1 = (unsigned)min(hj0, max(nnz_total - 1, 0));
-            const double2 f = beam_at(bxy + b1, i1);
-            fbx = f.x;
-            fby = f.y;
-        }
-    } else if (PPW > 1 && pp + 1 < PPW && tl + 1 < nloc) {   // the next pose's header and first beams, requested now
-        hj0 = j1;
-        hj1 = __builtin_amdgcn_readfirstlane(boff[tl + 2]);
-        pose_of(x, x0, t_begin + tl + 1, hpx, hpy, hth);
-        hct = rot[2 * (size_t)(tl + 1)];
-        hst = rot[2 * (size_t)(tl + 1) + 1];
-        const unsigned i1 = min((unsigned)lane, (unsigned)(nnz_total - j1) - 1u);   // (clamped to the shard's last beam)
-        const double2 f = beam_at(bxy + j1, i1);
-        fbx = f.x;
-        fby = f.y;
+    const int j0 = __builtin_amdgcn_readfirstlane(boff[tl]), j1 = __builtin_amdgcn_readfirstlane(boff[tl + 1]);
+    double px, py, th, ct, st;
+    pose_of(x, x0, t_begin + tl, px, py, th);
+    if (rot) {   // (cos, sin)(theta - pi/2) from the sweep's table: the same values, computed once
+        ct = rot[2 * (size_t)tl];
+        st = rot[2 * (size_t)tl + 1];
+    } else {
+        pose_rot(th, ct, st);
     }
     if (j0 == j1) {
         if (lane == 0) {
@@ -909,7 +845,14 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
             isnew_out[tl] = 0;
             st_off[tl] = 0;
         }
-        continue;
+        return;
+    }
+    double nbx, nby;   // the pose's first 64 beams
+    {
+        const unsigned i0 = min((unsigned)lane, (unsigned)(j1 - j0) - 1u);
+        const double2 f = beam_at(bxy + j0, i0);
+        nbx = f.x;
+        nby = f.y;
     }
     // this pose's reserved place (scalar loads, in flight while the beams are grouped)
     const int plan0 = __builtin_amdgcn_readfirstlane(plan[tl]), plan1 = __builtin_amdgcn_readfirstlane(plan[tl + 1]);
@@ -1055,8 +998,6 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         __threadfence_block();
         for (int j = j0 + lane; j < j1; j += kWave) bloc[j] = T.owner[bloc[j]];
     }
-    __builtin_amdgcn_wave_barrier();   // (the table is cleared for the wave's next pose)
-    }   // poses of this wave
 }
 
 // Running-mean term of one entry: sum of its beams' world points and their count.  One

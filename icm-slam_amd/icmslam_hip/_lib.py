@@ -99,7 +99,6 @@ SIGNATURES = {
     "icm_restore_state": (C.c_int, [_H]),
     "icm_set_colour_fusion": (C.c_int, [_H, C.c_int]),
     "icm_set_fold_mode": (C.c_int, [_H, C.c_int]),
-    "icm_set_assoc_persistence": (C.c_int, [_H, C.c_int]),
     "icm_get_fixup_poses": (C.c_int, [_H, _lp]),
     "icm_get_dropin_counts": (C.c_int, [_H, _lp]),
     "icm_staging_layout": (C.c_int, [C.c_int64, C.c_int64, _lp]),
@@ -109,6 +108,7 @@ SIGNATURES = {
     "icm_get_entry_path": (C.c_int, [_H]),
     "icm_set_energy_form": (C.c_int, [_H, C.c_int]),
     "icm_version": (C.c_char_p, []),
+    "icm_build_id": (C.c_char_p, []),
     "icm_flop_per_eval": (C.c_int, []),
     "icm_valu_per_eval": (C.c_int, []),
 }

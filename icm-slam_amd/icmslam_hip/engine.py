@@ -520,10 +520,6 @@ class SweepEngine:
         a second solve by the same wave, 0 the complete energy in the loop itself (icm_set_fold_mode)."""
         self._chk(self.lib.icm_set_fold_mode(self.h, int(mode)))
 
-    def set_assoc_persistence(self, workgroups_per_cu):
-        """Phase A on persistent waves: workgroups per compute unit (default 8); 0 = one wave per pose."""
-        self._chk(self.lib.icm_set_assoc_persistence(self.h, int(workgroups_per_cu)))
-
     def fixup_poses(self):
         """Poses solved a second time with the complete energy (an evaluation left the folded form's range), so far."""
         n = C.c_int64(0)

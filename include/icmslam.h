@@ -279,6 +279,7 @@ int icm_kernel_time(icm_handle *h, int idx, const char **name, double *ms, int64
  * new landmarks, [3] labels in use (landmarks_actuales before filtrar). */
 int icm_last_stats(const icm_handle *h, int64_t *out4);
 const char *icm_version(void);
+const char *icm_build_id(void);   /* first 16 hex digits of the sha256 of the sources the library was built from */
 /* FP64 flops (fma = 2) / vector instructions of ONE evaluation of the pose energy (reference
  * fun_xn, scripts/ICM_ROS.py:220-252, in the moment form the solve kernels use), counted at build
  * time from the gfx950 ISA of csrc/eval_probe.hip by tools/count_eval_flops.py. */

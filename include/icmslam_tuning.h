@@ -82,17 +82,6 @@ int icm_get_phase_times(const icm_handle *h, double *out5, int64_t *sweeps);
  * sharded job whose device failed: it must still take part in the sweep's collective, icm_sweep_sharded); 0 = off. */
 int icm_set_fault(icm_handle *h, int where);
 
-/* Launch form of phase A (k_assoc_group: tras_rot_z + Mapa.actualizar's association and per-scan grouping,
- * scripts/ICM_SLAM_tools.py:168-195), one wavefront per pose in every form:
- *    0  (default) four poses per 256-thread workgroup
- *   -1  one-wave workgroups: a wave slot is recycled the moment its pose is done instead of waiting for the longest scan
- *       of its group of four (measured: no difference, 0.1843 against 0.1848 ms at S2)
- *   n > 0  PERSISTENT waves, n workgroups of four waves per compute unit, each wave striding over the poses with the
- *       next pose's header and first beams already in flight (measured slower: static striding cannot balance scans
- *       of 0 .. 720 beams)
- * Same results. */
-int icm_set_assoc_persistence(icm_handle *h, int workgroups_per_cu);
-
 /* Sizes of the staging area of phase A's (pose, landmark) entries for a shard with nnz kept beams and nloc poses (host
  * arithmetic only, no GPU): out3 = [first place of the sparse area, capacity of the staged-entry arrays, capacity of
  * each per-entry prefix array].  ICM_ERR_CAPACITY when they exceed 32-bit entry offsets. */

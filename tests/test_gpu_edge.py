@@ -964,36 +964,6 @@ def test_fold_only_solve_on_the_dataset_sequential_and_redblack():
         assert np.array_equal(a, b)
 
 
-def test_phase_a_launch_forms_give_the_same_state():
-    """k_assoc_group as four poses per workgroup (-1), one-wave workgroups (0) and persistent striding waves (2 and 8
-    workgroups per CU, the first so few that every wave walks many poses): same entries, same state, bit for bit -- on
-    the dataset (scans of 0 .. 17 kept beams, 100 poses without any) and on a 1900-pose synthetic sequence."""
-    from ICM_SLAM_tools import ConfigICM
-    from icmslam_hip import SweepEngine
-    from icmslam_hip.synthetic import make_workload
-    from util import Cfg, dataset, gold
-    zz, odo, u = dataset()
-    init = gold("init_pass.npz")
-    wl = make_workload(1900, 100, 180)
-    cases = (("data_IJAC2018", Cfg(), (zz, odo, u), dict(), (init["map_init"], init["x_init"], odo[:, 0], int(init["landmarks_actuales"]))),
-             ("synthetic 1900", ConfigICM(D=wl.config), (wl.scans, wl.odometry, wl.u), dict(pose_major=True), (wl.map_init, wl.x_init, wl.x0, None)))
-    for name, cfg, seq, kw, state in cases:
-        ref = None
-        for form in (-1, 0, 2, 8):
-            eng = SweepEngine(cfg)
-            eng.upload(*seq, **kw)
-            eng.set_assoc_persistence(form)
-            eng.set_state(*state)
-            for _ in range(3):
-                eng.sweep_device("redblack")
-            got = eng.get_state() + (eng.raw_map()[0], eng.last_stats()["entries"])
-            eng.close()
-            if ref is None:
-                ref = got
-            for a, b in zip(ref, got):
-                assert np.array_equal(a, b), (name, form)
-
-
 def test_host_array_sweeps_reuse_the_device_map_only_when_it_is_the_same_map():
     """icm_sweep keeps the search grid of the last Mapa.filtrar when the caller hands back exactly the
     map it returned (the reference driver's mapa_viejo = copy(mapa_refinado)); any edit of the map --

@@ -60,13 +60,18 @@ def test_staging_layout_is_consistent_for_every_shape_of_shard():
 
 def test_shard_partition_cuts_at_even_poses():
     from icmslam_hip import _lib
-    from icmslam_hip.sharded import partition, shard_block
+    from icmslam_hip.sharded import partition, shard_block, world_fits
     lib = _lib.load()
     for T in (2, 3, 249, 600, 1833, 1900, 100_000, 800_000):
         for world in (1, 2, 3, 7, 8):
+            assert shard_block(T, world) == lib.icm_shard_block(T, world)
+            if not world_fits(T, world):      # (a trailing rank would be left without poses: refused)
+                with pytest.raises(ValueError):
+                    partition(T, world)
+                continue
             blk, parts = partition(T, world)
-            assert blk == shard_block(T, world) == lib.icm_shard_block(T, world) and blk % 2 == 0
-            assert parts[0][0] == 0 and parts[-1][1] == T and all(a % 2 == 0 for a, b in parts if b > a)   # (trailing ranks may be empty)
+            assert blk == shard_block(T, world) and blk % 2 == 0
+            assert parts[0][0] == 0 and parts[-1][1] == T and all(b > a and a % 2 == 0 for a, b in parts)
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             assert all(b - a == blk for a, b in parts if b < T)
 

@@ -1,17 +1,18 @@
 """Summarise rocprofv3 --pmc passes: mean counter value per dispatch, per kernel.
 usage: pmc_summary.py out.csv dir1 dir2 ...
-       pmc_summary.py --traffic profiles/traffic.json WORKLOAD traffic_summary.csv
+       pmc_summary.py --traffic profiles/traffic.json WORKLOAD traffic_summary.csv [BUILD_ID]
            -> HBM bytes per launch by bench.py's kernel names (what bench.py reports as roofline.traffic):
               (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950"""
 import csv, glob, os, sys, re, json
 
 BENCH_NAMES = (("k_assoc_group<false, false", "k_assoc_group"), ("k_chunk_l1", "k_chunk_l1"), ("k_chunk_l2", "k_chunk_l2"),
                ("k_lm_l3", "k_lm_l3"), ("k_rec_push", "k_rec_push"), ("k_pose_moments", "k_pose_moments"),
-               ("k_solve_m_fused", "k_solve"), ("k_solve_m_fix", "k_solve_deferred"), ("k_scan_", "k_scan"),
+               ("k_solve_m_fused", "k_solve"), ("k_scan_", "k_scan"),
                ("k_neigh_table", "k_neigh_table"), ("k_fl_", "k_filtrar"), ("k_pose_rot", "k_pose_rot"))
 
 if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
     dst, workload, src = sys.argv[2:5]
+    build = sys.argv[5] if len(sys.argv) > 5 else None    # icm_build_id() of the library that was profiled
     tj = json.load(open(dst)) if os.path.exists(dst) else {}
     per = {}
     for r in csv.DictReader(open(src)):
@@ -21,10 +22,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
                 break
     tj[workload] = per
     tj.setdefault("_source", {})[workload] = os.path.join("profiles", os.path.basename(src))
+    tj.setdefault("_build_id", {})[workload] = build
     tj["_note"] = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, KB units; FETCH doubled per "
                    "MI355X_MICROARCH.md: gfx950 counts 128-B reads at 64 B; the doubling is calibrated for wide streaming reads and "
-                   "over-counts narrow gathers); kernels launched several times per sweep (k_scan, k_filtrar, k_solve_deferred) are summed "
-                   "over their per-launch averages.  Written by tools/pmc_summary.py --traffic from the file named in _source.")
+                   "over-counts narrow gathers); kernels launched several times per sweep (k_scan, k_filtrar) are summed "
+                   "over their per-launch averages.  Written by tools/pmc_summary.py --traffic from the file named in _source; _build_id = "
+                   "icm_build_id() of the library that was profiled: bench.py reports the numbers only for that very build.")
     json.dump(tj, open(dst, "w"), indent=1, sort_keys=True)
     print(json.dumps(per, indent=1))
     sys.exit(0)

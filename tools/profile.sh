@@ -1,7 +1,7 @@
-# rocprofv3 passes behind profiles/r02_*: run on the GPU box from the repo root,
+# rocprofv3 passes behind profiles/rNN_*: run on the GPU box from the repo root (copy gpurun_out/TAG_* and gpurun_out/traffic.json into profiles/ afterwards),
 #   gpurun -- 'bash tools/profile.sh TAG'
 # kernel-trace/stats and the PMC passes are separate runs (the pool refuses them combined).
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --workload S2 --steps 6 --warmup 2 --cpu-poses 0 --no-roofline --no-extras"
 O=gpurun_out/prof_$TAG
@@ -16,3 +16,9 @@ python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_traffic_S2.csv $O/pmc_f $O/pm
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${TAG}_S2_kernel_stats.csv
 tail -1 $O.stats.log | cut -c1-400
 head -25 gpurun_out/${TAG}_S2_kernel_stats.csv
+# counter traffic per launch by bench.py's kernel names, stamped with the build that was profiled (bench.py reports it for that build only)
+BID=$(python3 -c "import sys; sys.path.insert(0, 'icm-slam_amd'); from icmslam_hip import _lib; print(_lib.load().icm_build_id().decode())")
+cp profiles/traffic.json gpurun_out/traffic.json 2>/dev/null
+python3 tools/pmc_summary.py --traffic gpurun_out/traffic.json S2 gpurun_out/${TAG}_pmc_traffic_S2.csv $BID > /dev/null
+sed -i "s#profiles/${TAG}_pmc_traffic_S2.csv#profiles/${TAG}_pmc_traffic_S2.csv#" gpurun_out/traffic.json
+echo "build $BID"
