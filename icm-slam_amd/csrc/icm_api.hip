@@ -237,6 +237,10 @@ struct icm_handle {
     DevBuf<double> rot;   // (cos, sin)(theta - pi/2) per pose of the shard, refreshed at the start of every sweep (k_pose_rot)
     hipEvent_t ev_map = nullptr, ev_copied = nullptr;
     bool map_ev_in_local = false;   // this sweep's ev_map is the stop event of k_lm_l3 (icm_sweep_local)
+    bool map_by_spinner = false;    // ... or there is no event: the side stream polls the word k_lm_l3's last workgroup sets
+    bool l3_spin = true;            // (ICM_L3_EVENT=1: the stop event, for A/B runs)
+    DevBuf<int> l3_done;            // [0] workgroups of k_lm_l3 through, [1] epoch of the launch that finished last, [2] epoch of a wait that gave up
+    int l3_epoch = 0;
     bool map_copy_pending = false;
 };
 
@@ -400,6 +404,7 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
         }
         h->thr2 = s2;
     }
+    if (const char* ev = std::getenv("ICM_L3_EVENT")) h->l3_spin = std::atoi(ev) == 0;
     h->own_stream = true;
     h->h_counts.assign((size_t)cfg->L, 0.0);
     *out = h;
@@ -435,6 +440,7 @@ int icm_destroy(icm_handle* h) {
     for (auto& e : h->ev_ph) if (e) (void)hipEventDestroy(e);
     if (h->ev_cmp) (void)hipEventDestroy(h->ev_cmp);
     h->x_stale.release();
+    h->l3_done.release();
     if (h->ev_gh0) (void)hipEventDestroy(h->ev_gh0);
     if (h->ev_gh1) (void)hipEventDestroy(h->ev_gh1);
     h->snap.x.release(); h->snap.mapx.release(); h->snap.mapy.release(); h->snap.counts_new.release();
@@ -946,6 +952,10 @@ static FiltrarArgs filtrar_args(icm_handle* h) {
         fa.stale = h->x_stale.p;
         fa.stale_epoch = h->x_epoch;
     }
+    if (h->map_by_spinner) {
+        fa.gave_up = h->l3_done.p + 2;
+        fa.gave_up_epoch = h->l3_epoch;
+    }
     return fa;
 }
 
@@ -1099,11 +1109,26 @@ int icm_sweep_local(icm_handle* h) {
                 // signal, no marker packet on the queue) starts the side stream's Mapa.filtrar, a kernel earlier than the end
                 // of k_rec_push.
                 const bool map_final = h->world == 1;
-                hipExtLaunchKernelGGL(k_lm_l3, dim3((L + kWave - 1) / kWave), dim3(kBlock), 0, h->stream, nullptr, map_final ? h->ev_map : nullptr, 0,
+                const bool spin = map_final && h->gpu_filtrar && h->l3_spin;
+                if (spin) {
+                    // ... or no event at all (round 4): a one-wave kernel on the side stream, queued NOW, polls a word that
+                    // k_lm_l3's last workgroup sets (raw map and flags out write-through); Mapa.filtrar, queued behind it
+                    // in icm_sweep_targets, starts a kernel boundary after the raw map is out, and nothing stands on the
+                    // main queue between k_lm_l3 and k_rec_push (the stop event cost 5-6 us there).
+                    if (!h->l3_done.p) {
+                        HIPCHK(h, h->l3_done.reserve(4));
+                        HIPCHK(h, hipMemset(h->l3_done.p, 0, 4 * sizeof(int)));
+                        h->l3_epoch = 0;
+                    }
+                    ++h->l3_epoch;
+                    k_wait_word<<<1, kWave, 0, h->copy_stream>>>(h->l3_done.p + 1, h->l3_epoch, 1 << 16, h->l3_done.p + 2);
+                }
+                hipExtLaunchKernelGGL(k_lm_l3, dim3((L + kWave - 1) / kWave), dim3(kBlock), 0, h->stream, nullptr, (map_final && !spin) ? h->ev_map : nullptr, 0,
                     h->nsuper, L, h->lact0, (const int*)(run_scan ? h->new_rank.p + nloc : h->fl + 9), ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p,
                     (const int*)(run_scan ? h->ent_off.p + nloc : h->fl + 8), h->fl, 0, -1, (const double*)nullptr, (double*)nullptr, 1,
-                    h->flags.p + 16 * (h->fl_parity ^ 1), h->pin_i_dev, map_final ? 1 : 0);
+                    h->flags.p + 16 * (h->fl_parity ^ 1), h->pin_i_dev, map_final ? 1 : 0, spin ? h->l3_done.p : (int*)nullptr, h->l3_epoch);
                 h->map_ev_in_local = map_final;
+                h->map_by_spinner = spin;
             } else
             TIMED(h, KID_LM_L3, (k_lm_l3<<<(L + kWave - 1) / kWave, kBlock, 0, h->stream>>>(h->nsuper, L, h->lact0, run_scan ? h->new_rank.p + nloc : h->fl + 9, ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p, run_scan ? h->ent_off.p + nloc : h->fl + 8, h->fl, 0, -1, nullptr, nullptr, 1, h->flags.p + 16 * (h->fl_parity ^ 1))));
             h->fl_next_clean = true;
@@ -1309,8 +1334,10 @@ int icm_sweep_targets(icm_handle* h) {
     HIPCHK(h, hipGetLastError());
     // The raw map (and, sharded, the ranks' new-landmark counts) is final here: start its
     // download on the copy stream so that Mapa.filtrar on the host overlaps the pose solves.
-    if (!ev_map_recorded) HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
+    if (!(h->map_ev_in_local && h->map_by_spinner)) {   // (else the side stream already waits for the raw map: k_wait_word)
+        if (!ev_map_recorded) HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
+    }
     const size_t Ls = (size_t)L;
     if (h->world > 1)
         for (int r = 0; r < h->world && r < 64; ++r)

@@ -1600,7 +1600,10 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
                                                   int row_begin = 0, int row_end = -1, const double* __restrict__ carry_in = nullptr,
                                                   double* __restrict__ carry_out = nullptr, int final = 1,
                                                   int* __restrict__ flags_next = nullptr, int* __restrict__ host_words = nullptr,
-                                                  int host_flags = 0) {
+                                                  int host_flags = 0, int* __restrict__ done = nullptr, int done_epoch = 0) {
+    // done (nullable): [0] workgroups of this launch that are through (the last one resets it), [1] := done_epoch by the
+    // last one -- the side stream's k_wait_word polls it: Mapa.filtrar starts the moment the raw map is out, without a
+    // stop event on this queue (5-6 us of nothing behind this launch).  The raw map and the flags go out write-through.
     __shared__ double tot[3][kL3Groups][kWave];
     const int col = threadIdx.x & (kWave - 1), grp = threadIdx.x >> 6;
     const int i = blockIdx.x * kWave + col;
@@ -1611,6 +1614,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
         flags[6] = flags[0];
         flags[7] = flags[1];
         flags[2] = lact0 + *n_new_dev > L ? 1 : 0;   // labels beyond the map capacity (the reference's IndexError)
+        if (done) __hip_atomic_store(&flags[2], flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by a kernel that does not wait for this launch's end)
         // the NEXT sweep's flag block (the sweeps alternate between two): nobody reads it any more -- the sweep before this
         // one is over, host included -- and clearing it here saves the next sweep a memset launch at its head
         if (flags_next)
@@ -1671,23 +1675,53 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
             }
         }
     }
-    if (grp != kL3Groups - 1 || i >= L) return;   // the last group holds the column totals
-    ax += tx; ay += ty; an += tn;
-    if (carry_out) {
-        carry_out[i] = ax;
-        carry_out[L + i] = ay;
-        carry_out[2 * (size_t)L + i] = an;
+    if (grp == kL3Groups - 1 && i < L) {   // the last group holds the column totals
+        ax += tx; ay += ty; an += tn;
+        if (carry_out) {
+            carry_out[i] = ax;
+            carry_out[L + i] = ay;
+            carry_out[2 * (size_t)L + i] = an;
+        }
+        if (final && stats) {
+            stats[i] = ax;
+            stats[L + i] = ay;
+            stats[2 * L + i] = an;
+        } else if (final) {
+            const double mx = an > 0.0 ? ax / an : 0.0, my = an > 0.0 ? ay / an : 0.0;
+            if (done) {
+                __hip_atomic_store(&cnt_raw[i], an, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&y_raw[i], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&y_raw[L + i], my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                cnt_raw[i] = an;
+                y_raw[i] = mx;
+                y_raw[L + i] = my;
+            }
+        }
     }
-    if (!final) return;
-    if (stats) {
-        stats[i] = ax;
-        stats[L + i] = ay;
-        stats[2 * L + i] = an;
-    } else {
-        cnt_raw[i] = an;
-        y_raw[i] = an > 0.0 ? ax / an : 0.0;
-        y_raw[L + i] = an > 0.0 ? ay / an : 0.0;
+    if (done) {   // (block-uniform)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(&done[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (int)gridDim.x - 1) {
+                __hip_atomic_store(&done[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&done[1], done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
+}
+
+// One wave on the side stream waits for a word to take a value (k_lm_l3's last workgroup: the raw map is out): what
+// is queued behind it starts then, a kernel boundary later.  Bounded (the launch that would set the word may have
+// failed): on giving up it raises *give_up, and Mapa.filtrar, queued behind, leaves the map alone (the sweep is repeated).
+__global__ __launch_bounds__(kWave) void k_wait_word(const int* __restrict__ word, int value, int polls, int* __restrict__ give_up) {
+    if (threadIdx.x != 0) return;
+    for (int p = 0; p < polls; ++p) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == value) return;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    *give_up = value;
 }
 
 // Sums before each record's chunk: lower ranks (rank_*; null on a single rank) + the
@@ -1777,6 +1811,8 @@ struct FiltrarArgs {
     double* host_map = nullptr; // nullable: [x (L) | y (L) | counters (L)] in the host's mapped memory: k_fl_finalize writes the refined map there as well
     const int* stale = nullptr; // nullable: *stale == stale_epoch = this sweep ran from poses that were not the caller's (SolveSeg::stale)
     int stale_epoch = 0;
+    const int* gave_up = nullptr;   // nullable: *gave_up == gave_up_epoch = the wait for the raw map in front of this chain gave up (k_wait_word)
+    int gave_up_epoch = 0;
 };
 
 __device__ __forceinline__ int block_exscan_1024(int v, int* wsum, int& total) {
@@ -1893,7 +1929,8 @@ __global__ __launch_bounds__(kFB) void k_fl_count(FiltrarArgs a, int chunk) {
         a.st->part_keep[b] = tot;
         if (b == 0) {
             a.st->close = a.st->same = a.st->host = 0;
-            a.st->abort = (a.sweep_flags ? (a.sweep_flags[0] | a.sweep_flags[1] | a.sweep_flags[2]) : 0) | ((a.stale && *a.stale == a.stale_epoch) ? 1 : 0);
+            a.st->abort = (a.sweep_flags ? (a.sweep_flags[0] | a.sweep_flags[1] | a.sweep_flags[2]) : 0) | ((a.stale && *a.stale == a.stale_epoch) ? 1 : 0) |
+                          ((a.gave_up && *a.gave_up == a.gave_up_epoch) ? 1 : 0);
         }
     }
 }
