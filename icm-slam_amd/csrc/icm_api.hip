@@ -205,6 +205,7 @@ struct icm_handle {
     hipEvent_t ev_ph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double ph_ms[5] = {0, 0, 0, 0, 0};   // local | exchange (+ waiting for the slowest rank) | targets | solve | host time in finish
     int64_t ph_n = 0;
+    int solve_ppw = 0;   // poses per wave of the one-launch solve: 0 automatic, 32 or 64 (ICM_SOLVE_PPW)
     int fault = 0;   // test hook (icm_set_fault): 1 = the next icm_sweep_local reports a HIP error
     int64_t dropin_counts[3] = {0, 0, 0};   // icm_sweep calls: [0] started without an upload, [1] of those: the check failed (started over), [2] poses mirrored into the caller's array
     double h_x0[3] = {0, 0, 0};      // host copy of x0 as uploaded
@@ -405,6 +406,7 @@ int icm_create(const icm_config* cfg, int device, icm_handle** out) {
         h->thr2 = s2;
     }
     if (const char* ev = std::getenv("ICM_L3_EVENT")) h->l3_spin = std::atoi(ev) == 0;
+    if (const char* ev = std::getenv("ICM_SOLVE_PPW")) h->solve_ppw = std::atoi(ev);
     h->own_stream = true;
     h->h_counts.assign((size_t)cfg->L, 0.0);
     *out = h;
@@ -1396,7 +1398,11 @@ static SolveSeg shard_segment(const icm_handle* h, const int* abort) {
 // behind it: poses outside the folded form's range and even waves that deferred are dealt with inside the launch.
 static int launch_fused_solve(icm_handle* h, SolveArgs a, SolveSeg g, hipStream_t st) {
     const int64_t npc = (g.t1 - g.t0) / 2 + 1;   // poses per colour (upper bound)
-    const int nwv = (int)((npc + kWave - 1) / kWave);   // (fewer poses per lane-form wave was measured: 32 at S1 -8 %, 2 at 600 poses +38 %: not adopted)
+    // poses per wave: 64, or 32 while both colours' half-filled waves still find a SIMD each twice over (S1, the shards of
+    // an 8-rank job): a wave lasts as long as its slowest lane (ICM_SOLVE_PPW: A/B runs)
+    int ppw = (4 * (int64_t)((npc + 31) / 32) <= 4 * (int64_t)h->cu_count) ? 32 : kWave;
+    if (h->solve_ppw == 32 || h->solve_ppw == 64) ppw = h->solve_ppw;
+    const int nwv = (int)((npc + ppw - 1) / ppw);
     if (h->solve_flag_waves < nwv) {
         HIPCHK(h, hipStreamSynchronize(h->stream));   // (re-allocation: nothing may still be polling the old flags)
         if (h->solve_stream) HIPCHK(h, hipStreamSynchronize(h->solve_stream));
@@ -1423,9 +1429,9 @@ static int launch_fused_solve(icm_handle* h, SolveArgs a, SolveSeg g, hipStream_
     const bool zero_here = zn > 0 && zn <= (size_t)nwv * kWave * 64 && zn < (1ull << 32);
     double* const zo = zero_here ? h->ms.p : nullptr;
     if (fold)
-        TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred, sync, h->solve_counts.p, zo, (unsigned)(zero_here ? zn : 0))));
+        TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred, sync, h->solve_counts.p, zo, (unsigned)(zero_here ? zn : 0), ppw)));
     else
-        TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred, sync, h->solve_counts.p, zo, (unsigned)(zero_here ? zn : 0))));
+        TIMED(h, KID_SOLVE, (k_solve_m_fused<false><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred, sync, h->solve_counts.p, zo, (unsigned)(zero_here ? zn : 0), ppw)));
     if (zero_here) h->ms_clean = true;
     HIPCHK(h, hipGetLastError());
     return ICM_OK;

@@ -2734,7 +2734,10 @@ template <bool FOLD>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void k_solve_m_fused(SolveArgs a, SolveSeg g, int nw, int* __restrict__ flags,
                                                           int spin_limit, int* __restrict__ deferred, int* __restrict__ sync,
                                                           unsigned long long* __restrict__ counts,
-                                                          double* __restrict__ zero_out = nullptr, unsigned zero_n = 0) {
+                                                          double* __restrict__ zero_out = nullptr, unsigned zero_n = 0, int ppw = kWave) {
+    // ppw: poses per wave, 64 or (short colours: fewer waves than the chip has SIMDs either way) 32 -- a wave lasts as
+    // long as its slowest lane and an even wave waits for the slowest of its two odd waves' lanes: half-filled waves
+    // shorten both maxima
     const int lane = lane_id();
     const int gw = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (gw >= 2 * nw) return;
@@ -2751,8 +2754,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
     const int epoch = a.epoch;
     const bool even = gw >= nw;
     const int wv = even ? gw - nw : gw;
-    const int tg = seg_pose(g, even, wv * kWave + lane);
-    const bool mine = tg < g.t1;
+    const int tg = seg_pose(g, even, wv * ppw + lane);
+    const bool mine = lane < ppw && tg < g.t1;
     WAVE_TS(0);
     // everything this launch does not write -- moment sums, odometry, controls, the pose's own previous value and the
     // trigonometry kept beside them -- is requested BEFORE an even wave starts to wait for its odd neighbours
@@ -2877,8 +2880,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
         }
         if (found < 0) return;
         scan_from = found + 1;
-        tgc = seg_pose(g, true, found * kWave + lane);
-        redo = tgc < g.t1;
+        tgc = seg_pose(g, true, found * ppw + lane);
+        redo = lane < ppw && tgc < g.t1;
     }
 }
 
