@@ -276,6 +276,8 @@ struct icm_handle {
         }                                                                      \
     } while (0)
 
+constexpr int kStalePoses = 1001;   // internal (icm_sweep_finish -> icm_sweep): the sweep ran from device poses that were not the caller's; nothing was replaced
+constexpr int kStaleWord = 20;      // of the host's mapped block: the epoch of the call whose pose check failed
 static inline double host_now_ms() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -718,6 +720,14 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->ghost_n = gb[1];
     }
+    // the hand-off words of the sweep's side launches (k_wait_word / k_lm_l3, k_x_compare): cleared here, in stream order, in
+    // front of the synchronisation below -- never beside a launch that polls them (hipMemset on the null stream is not
+    // ordered against the handle's non-blocking streams)
+    HIPCHK(h, h->l3_done.reserve(4)); HIPCHK(h, h->x_stale.reserve(2));
+    HIPCHK(h, hipMemsetAsync(h->l3_done.p, 0, 4 * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->x_stale.p, 0, 2 * sizeof(int), h->stream));
+    h->l3_epoch = h->x_epoch = 0;
+    h->pin_i[kStaleWord] = 0;
     size_t tmp_bytes = 0;
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->e_key.p, h->skey.p, h->e_val.p, h->sval.p, nz, 0, 32, h->stream));
     HIPCHK(h, h->sort_tmp.reserve(tmp_bytes + 256));
@@ -831,8 +841,6 @@ int icm_set_state(icm_handle* h, const double* x, const double* x0, const double
 // results: what the neighbours need as OLD values (the rank above: the two poses around its ghost solve; the rank
 // below: the pose after its last odd pose).  One message, one collective per sweep.
 constexpr int kStatsHeader = 16;
-constexpr int kStalePoses = 1001;   // internal (icm_sweep_finish -> icm_sweep): the sweep ran from device poses that were not the caller's; nothing was replaced
-constexpr int kStaleWord = 20;      // of the host's mapped block: the epoch of the call whose pose check failed
 int64_t icm_stats_stride(const icm_handle* h) { return h ? 3 * h->cfg.L + kStatsHeader : 0; }
 
 int icm_bind_exchange(icm_handle* h, void* stats_all_dev, int rank, int world) {
@@ -1117,11 +1125,6 @@ int icm_sweep_local(icm_handle* h) {
                     // k_lm_l3's last workgroup sets (raw map and flags out write-through); Mapa.filtrar, queued behind it
                     // in icm_sweep_targets, starts a kernel boundary after the raw map is out, and nothing stands on the
                     // main queue between k_lm_l3 and k_rec_push (the stop event cost 5-6 us there).
-                    if (!h->l3_done.p) {
-                        HIPCHK(h, h->l3_done.reserve(4));
-                        HIPCHK(h, hipMemset(h->l3_done.p, 0, 4 * sizeof(int)));
-                        h->l3_epoch = 0;
-                    }
                     ++h->l3_epoch;
                     k_wait_word<<<1, kWave, 0, h->copy_stream>>>(h->l3_done.p + 1, h->l3_epoch, 1 << 16, h->l3_done.p + 2);
                 }
@@ -1978,12 +1981,6 @@ int icm_get_state(icm_handle* h, double* x, double* map_out, double* counts_out,
 static int sweep_without_upload(icm_handle* h, const double* xa, const double* x0, int schedule) {
     const size_t T = (size_t)h->T;
     HIPCHK(h, hipSetDevice(h->device));
-    if (!h->x_stale.p) {
-        HIPCHK(h, h->x_stale.reserve(1));
-        HIPCHK(h, hipMemset(h->x_stale.p, 0, sizeof(int)));
-        h->pin_i[kStaleWord] = 0;
-        h->x_epoch = 0;
-    }
     ++h->x_epoch;
     if (std::memcmp(x0, h->h_x0, sizeof(h->h_x0)) != 0) {
         std::memcpy(h->h_x0, x0, sizeof(h->h_x0));
