@@ -1426,10 +1426,11 @@ static int launch_fused_solve(icm_handle* h, SolveArgs a, SolveSeg g, hipStream_
     const bool iso = h->cfg.Q[0] == h->cfg.Q[1] && h->cfg.R[0] == h->cfg.R[1];
     const bool fold = h->fold_mode < 0 ? iso : h->fold_mode == 1;
     const int nb2 = nblocks_waves(2 * nwv);
-    // phase B's matrix, cleared for the next sweep by the launch's waiting even waves (when that is a few dozen stores per
-    // lane; else, and after any other solve launch, the next sweep clears it itself: ms_clean)
+    // phase B's matrix, cleared for the next sweep by the launch's waiting even waves (when that is at most a few hundred
+    // stores per lane; else, and after any other solve launch, the next sweep clears it itself: ms_clean)
     const size_t zn = h->path_used == 1 && !h->ms_clean ? 3 * (size_t)h->nsuper * (size_t)h->cfg.L : 0;
-    const bool zero_here = zn > 0 && zn <= (size_t)nwv * kWave * 64 && zn < (1ull << 32);
+    const bool zero_here = zn > 0 && zn <= (size_t)nwv * kWave * 256 && zn < (1ull << 32);   // (<= 256 stores per lane, one per poll of a ~40 us wait;
+                                                                                             //  64 left S1 and the shards of an 8-rank job a 6 us memset per sweep)
     double* const zo = zero_here ? h->ms.p : nullptr;
     if (fold)
         TIMED(h, KID_SOLVE, (k_solve_m_fused<true><<<nb2, kBlock, 0, st>>>(a, g, nwv, h->solve_flags.p, h->fused_spin_limit, deferred, sync, h->solve_counts.p, zo, (unsigned)(zero_here ? zn : 0), ppw)));
