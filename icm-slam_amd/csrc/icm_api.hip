@@ -238,6 +238,8 @@ struct icm_handle {
     DevBuf<double> rot;   // (cos, sin)(theta - pi/2) per pose of the shard, refreshed at the start of every sweep (k_pose_rot)
     hipEvent_t ev_map = nullptr, ev_copied = nullptr;
     bool map_ev_in_local = false;   // this sweep's ev_map is the stop event of k_lm_l3 (icm_sweep_local)
+    bool defer_filtrar = false;     // set by the library's own sweep drivers: Mapa.filtrar's launches are queued behind the solve launch (icm_sweep_targets)
+    bool filtrar_deferred = false;  // ... and this sweep's are still to be queued
     bool map_by_spinner = false;    // ... or there is no event: the side stream polls the word k_lm_l3's last workgroup sets
     bool l3_spin = true;            // (ICM_L3_EVENT=1: the stop event, for A/B runs)
     DevBuf<int> l3_done;            // [0] workgroups of k_lm_l3 through, [1] epoch of the launch that finished last, [2] epoch of a wait that gave up
@@ -1040,6 +1042,7 @@ int icm_sweep_local(icm_handle* h) {
         FAIL(h, ICM_ERR_HIP, "icm_sweep_local: injected fault (icm_set_fault)");
     }
     h->optimistic = h->opt_req && optimistic_applies(h);
+    h->filtrar_deferred = false;
     const int nloc = (int)h->nloc, L = (int)h->cfg.L;
     if (h->phase_timing) (void)hipEventRecord(h->ev_ph[0], h->stream);
     // pose 0 without kept beams: the reference returns its inputs untouched
@@ -1270,6 +1273,8 @@ int icm_exchange_status(icm_handle* h, int* rank_out, int* code_out, int* retry_
 
 int icm_failed_rank(icm_handle* h, int* rank_out, int* code_out) { return icm_exchange_status(h, rank_out, code_out, nullptr); }
 
+static int queue_filtrar(icm_handle* h, bool ev_map_recorded);
+
 // After the (optional) all-gather: offsets, raw map, targets.
 int icm_sweep_targets(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
@@ -1337,8 +1342,21 @@ int icm_sweep_targets(icm_handle* h) {
     if (h->assoc_kept)
         TIMED(h, KID_BEAM_TARGETS, (k_beam_targets<<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(nloc, h->boff.p, h->ent_off.p, h->bloc.p, h->tgt.p, h->btx.p, h->bty.p)));
     HIPCHK(h, hipGetLastError());
-    // The raw map (and, sharded, the ranks' new-landmark counts) is final here: start its
-    // download on the copy stream so that Mapa.filtrar on the host overlaps the pose solves.
+    // Mapa.filtrar on the side stream.  When that stream waits for the raw map by itself (k_wait_word) and the caller is
+    // this library's own sweep driver, its nine launches are queued BEHIND the solve launch (icm_sweep_solve): on short
+    // sequences the host is what the main queue waits for, and the solve launch must not stand behind them in the
+    // host's launch order.
+    if (h->defer_filtrar && h->map_ev_in_local && h->map_by_spinner && !h->timing) {
+        h->filtrar_deferred = true;
+        return ICM_OK;
+    }
+    return queue_filtrar(h, ev_map_recorded);
+}
+
+// The raw map (and, sharded, the ranks' new-landmark counts) is final: Mapa.filtrar on the side stream, overlapping the
+// pose solves; the host's one wait of the sweep is for ev_copied.
+static int queue_filtrar(icm_handle* h, bool ev_map_recorded) {
+    const int L = (int)h->cfg.L;
     if (!(h->map_ev_in_local && h->map_by_spinner)) {   // (else the side stream already waits for the raw map: k_wait_word)
         if (!ev_map_recorded) HIPCHK(h, hipEventRecord(h->ev_map, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_map, 0));
@@ -1361,6 +1379,7 @@ int icm_sweep_targets(icm_handle* h) {
         HIPCHK(h, hipMemcpyAsync(h->pin_i + 12, h->fl, 4 * sizeof(int), hipMemcpyDeviceToHost, h->copy_stream));   // single rank: k_lm_l3 wrote them)  ([3]: poses outside their reserved staging place)
     HIPCHK(h, hipEventRecord(h->ev_copied, h->copy_stream));
     h->map_copy_pending = true;
+    h->filtrar_deferred = false;
     return ICM_OK;
 }
 
@@ -1509,6 +1528,7 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
     }
     HIPCHK(h, hipGetLastError());
     if (ph) (void)hipEventRecord(h->ev_ph[4], h->stream);
+    if (h->filtrar_deferred) return queue_filtrar(h, true);
     return ICM_OK;
 }
 
@@ -1709,8 +1729,11 @@ static int icm_sweep_classic(icm_handle* h, int schedule) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         h->opt_req = attempt == 0 && schedule == ICM_SCHEDULE_REDBLACK;
         rc = icm_sweep_local(h);
+        h->defer_filtrar = true;    // (targets and solve are called back to back here)
         if (!rc) rc = icm_sweep_targets(h);
         if (!rc) rc = icm_sweep_solve(h, schedule, -1);
+        h->defer_filtrar = false;
+        if (!rc && h->filtrar_deferred) rc = queue_filtrar(h, true);   // (the solve call returned early: scan 0 without beams)
         if (!rc) rc = icm_sweep_finish(h);
         if (rc != ICM_RETRY_CAREFUL) break;
         if (h->x_check && h->pin_i[kStaleWord] == h->x_epoch) { rc = kStalePoses; break; }   // (the flags mean nothing then)
