@@ -1499,7 +1499,12 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         if (h->world != 1) FAIL(h, ICM_ERR_UNSUPPORTED, "the sequential (reference-order) schedule is one dependent chain and cannot be sharded");
         if (h->form == 1) TIMED(h, KID_SOLVE, (k_solve_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
         else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_sequential<false><<<1, kWave, 0, h->stream>>>(a)));
-        else TIMED(h, KID_SOLVE, (k_solve_m_sequential<<<1, kWave, 0, h->stream>>>(a)));
+        else {
+            const bool iso = h->cfg.Q[0] == h->cfg.Q[1] && h->cfg.R[0] == h->cfg.R[1];
+            if (h->fold_mode < 0 ? iso : h->fold_mode == 1) TIMED(h, KID_SOLVE, (k_solve_m_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
+            else TIMED(h, KID_SOLVE, (k_solve_m_sequential<false><<<1, kWave, 0, h->stream>>>(a)));
+            h->rot_valid = false;   // (the chain does not keep the rotation pairs: k_pose_rot at the head of the next sweep)
+        }
     } else if (schedule == ICM_SCHEDULE_REDBLACK && colour < 0 && h->form == 0 && h->fuse_colours && h->solve_quad != 1) {
         // both colours in one launch, even waves chase the odd ones (a shard: its ghost pose is the first odd pose)
         int rc = launch_fused_solve(h, a, shard_segment(h, abort), h->stream);

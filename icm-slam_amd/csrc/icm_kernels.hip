@@ -2899,17 +2899,38 @@ __global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, SolveSe
     if (role == 0) store_pose(a, tg, res, false);
 }
 
-// Reference order, moment form: one DPP quad walks the chain t = 1..T-1 (latency form of the
-// Nelder-Mead: the chain is strictly serial, so evaluation latency is all that matters).
+// Reference order (scripts/ICM_ROS.py:141: t = 1 .. T-1, every pose from its just-solved predecessor), moment form.
+// Round 4: ONE lane walks the chain (the quad form's broadcasts no longer pay since the folded energy: an evaluation is
+// a sixth of an iteration).  The inputs of pose t + 1 that do not depend on pose t's result (moment sums, odometry,
+// controls, its own previous value) are requested before pose t is solved; the Nelder-Mead loop evaluates the folded
+// energy only (FOLD: isotropic weights) and a pose that leaves its range is solved once more with the complete energy;
+// the rotation pairs kept beside the poses are NOT written here -- two generic sincos per pose on a chain of T - 1
+// solves -- but by k_pose_rot at the head of the next sweep, in parallel (the host clears rot_valid).  data_IJAC2018:
+// 53 -> ?? ms per sweep; the same arithmetic per pose as every other solve form (bit-identical).
+template <bool FOLD>
 __global__ __launch_bounds__(kWave) void k_solve_m_sequential(SolveArgs a) {
-    if (threadIdx.x >= 4) return;
-    const int role = threadIdx.x;
+    if (threadIdx.x != 0) return;
     double prev[3] = {a.x[0], a.x[1], a.x[2]};
+    PoseIn cur;
+    cur.n = 0;
+    if (a.T > 1) load_pose_in(a, 1, cur);
     for (int tg = 1; tg < a.T; ++tg) {
-        double res[3];
-        solve_pose_moments<true>(a, tg, prev, false, res, role);   // (prev is the pose this lane has just solved)
-        if (role == 0) store_pose(a, tg, res, false);
-        prev[0] = res[0]; prev[1] = res[1]; prev[2] = res[2];
+        PoseIn nxt;
+        nxt.n = 0;
+        if (tg + 1 < a.T) load_pose_in(a, tg + 1, nxt);
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+        bool ok = solve_pose_in<false, FOLD>(a, tg, cur, prev, false, r0, r1, r2);   // (prev is the pose this lane has just solved: its pair is formed here)
+        if (FOLD && !ok) {
+            int tgc = tg;
+            asm volatile("" : "+v"(tgc));
+            double res[3];
+            solve_pose_moments<false, false>(a, tgc, prev, false, res);
+            r0 = res[0]; r1 = res[1]; r2 = res[2];
+        }
+        const double res[3] = {r0, r1, r2};
+        store_pose_xyz(a, tg, res, false);
+        prev[0] = r0; prev[1] = r1; prev[2] = r2;
+        cur = nxt;
     }
 }
 
@@ -3051,18 +3072,48 @@ __global__ __launch_bounds__(kWave) void k_init_pass(InitArgs a) {
                 lty[j] = a.y[a.L + llab[j]];
             }
             __builtin_amdgcn_wave_barrier();
-            SolveCtx c;
-            c.dt = a.dt; c.R0 = a.R0; c.R1 = a.R1; c.R2 = a.R2; c.Q0 = a.Q0; c.Q1 = a.Q1; c.cte = a.cte;
-            const double ua[2] = {v, w}, zero3[3] = {0, 0, 0}, zero2[2] = {0, 0};
-            double oa[3], ot[3];
-            load3(a.odo, a.T, t - 1, oa);
-            load3(a.odo, a.T, t, ot);
-            make_ctx(c, 0, xt, zero3, ua, zero2, oa, ot, zero3);
-            Items it{a.bx + j0, a.by + j0, ltx, lty, nullptr, 0.0, 0.0, 0.0, n, nullptr, nullptr};
-            double out[6];
-            nelder_mead3([&](double px, double py, double th) { return pose_energy(c, it, px, py, th, lane); },
-                         c.gax, c.gay, c.gat, out);
-            xt[0] = out[0]; xt[1] = out[1]; xt[2] = out[2];
+            // The one-sided solve (fun_x / minimizar_x, scripts/ICM_ROS.py:254-278) in the moment form the sweeps use (round 4;
+            // the per-beam sum with a wave reduction per evaluation took 52 us per pose): the wave forms the pose's 14 sums
+            // once, about the prediction (the Nelder-Mead's start), one term per beam (an entry of one beam: no scatter
+            // term); then the folded energy, every lane running the same chain on the same numbers.
+            PoseIn in;
+            in.n = n;
+            in.ua0 = v; in.ua1 = w; in.ut0 = in.ut1 = 0.0;
+            load3(a.odo, a.T, t - 1, in.oa);
+            load3(a.odo, a.T, t, in.ot);
+            in.op[0] = in.op[1] = in.op[2] = 0.0;
+            in.coa = cos(in.oa[2]); in.soa = sin(in.oa[2]); in.cot = 1.0; in.sot = 0.0;
+            in.pox = xc0; in.poy = xc1; in.tho = xc2; in.co = cos(xc2); in.so = sin(xc2);
+            {
+                double m[kMomentCount];
+#pragma unroll
+                for (int q = 0; q < kMomentCount; ++q) m[q] = 0.0;
+                for (int j = lane; j < n; j += kWave) {
+                    const double bxx = a.bx[j0 + j], byy = a.by[j0 + j];
+                    const double wx = ct * bxx - st * byy, wy = st * bxx + ct * byy;
+                    const double rx = (xc0 + wx) - ltx[j], ry = (xc1 + wy) - lty[j];
+                    m[0] += 1.0; m[1] += wx; m[2] += wy; m[3] += rx; m[4] += ry;
+                    m[5] += wx * wx; m[6] += wy * wy; m[7] += wx * wy;
+                    m[8] += wx * rx; m[9] += wy * rx; m[10] += wx * ry; m[11] += wy * ry;
+                    m[12] += rx * rx; m[13] += ry * ry;
+                }
+#pragma unroll
+                for (int q = 0; q < kMomentCount; ++q) in.pm[q] = wave_sum(m[q]);
+                in.pm[14] = in.pm[15] = in.pm[16] = 0.0;
+            }
+            SolveArgs sa;
+            sa.x = a.x; sa.x0 = nullptr; sa.odo = a.odo; sa.u = a.u;
+            sa.T = t + 1;   // (one-sided: pose t is the last one there is)
+            sa.t_begin = 0; sa.nloc = a.T;
+            sa.dt = a.dt; sa.R0 = a.R0; sa.R1 = a.R1; sa.R2 = a.R2; sa.Q0 = a.Q0; sa.Q1 = a.Q1; sa.cte = a.cte;
+            sa.diag = nullptr; sa.rot = nullptr; sa.cs = nullptr; sa.odo_cs = nullptr; sa.epoch = 0; sa.xh = nullptr;
+            sa.ghost_n = 0; sa.ghost_m = nullptr;
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+            const bool iso = a.Q0 == a.Q1 && a.R0 == a.R1;
+            bool ok = false;
+            if (iso) ok = solve_pose_in<false, true>(sa, t, in, xt, false, r0, r1, r2);
+            if (!ok) solve_pose_in<false, false>(sa, t, in, xt, false, r0, r1, r2);
+            xt[0] = r0; xt[1] = r1; xt[2] = r2;
         }
         if (lane == 0) {
             a.x[3 * (size_t)t] = xt[0];
