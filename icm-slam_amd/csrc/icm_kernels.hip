@@ -452,6 +452,18 @@ __global__ __launch_bounds__(kBlock) void k_odo_trig(const double* __restrict__ 
     out[2 * (size_t)t + 1] = sin(th);
 }
 
+// v = mask bit of the lane ? if_set : if_clear, the mask in a scalar register pair (one v_cndmask, no per-lane boolean)
+__device__ __forceinline__ int mask_select(unsigned long long m, int if_set, int if_clear) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int mask_select_or_minus1(unsigned long long m, int if_set) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, -1, %1, %2" : "=v"(r) : "v"(if_set), "s"(m));
+    return r;
+}
+
 // Gated nearest landmark of the world point (wx, wy).  The three cell rows around the point
 // are three contiguous ranges of the cell-sorted table; they are walked as ONE loop so the
 // wave iterates max-over-lanes of the candidate COUNT (about 1.5 on average), not three
@@ -524,8 +536,13 @@ __device__ __forceinline__ int assoc_grid(const GridView& g, const GridParams& g
     const double s0 = dx * dx + dy * dy;
     dx = p1.x - wx; dy = p1.y - wy;
     const double s1 = dx * dx + dy * dy;
-    dx = p2.x - wx; dy = p2.y - wy;
-    double s2 = dx * dx + dy * dy;   // (kNeighFast == 2: what an empty slot gives, for the lanes that do not read theirs below)
+    // (kNeighFast == 2: what an empty slot gives a lane that does not read its slots 2 / 3 below -- (inf - wx)^2 + wy^2 is
+    // +inf for every finite point, and a non-finite point ends with no label whichever of inf / NaN stands here)
+    double s2 = __builtin_huge_val();
+    if (kNeighFast >= 3) {
+        dx = p2.x - wx; dy = p2.y - wy;
+        s2 = dx * dx + dy * dy;
+    }
     double s3 = s2;
     int id2 = kNeighFast >= 3 ? ic.w : -1, id3 = -1;
     // The rest of the record, for the lanes whose neighbourhood holds more candidates than that -- and only when the wave
@@ -560,21 +577,29 @@ __device__ __forceinline__ int assoc_grid(const GridView& g, const GridParams& g
     // Two-slot form (no lane of the wave has a third candidate): what the four-slot form below gives when slots 2 and 3
     // are empty -- fmin skips a NaN, an infinite s2 is "within the limit" only when every candidate's distance is infinite
     // too, and then slot 0 or 1 is picked first either way.
-    double best, lim;
-    bool c0, c1, c2 = false, c3 = false;
+    // The decision is lane-mask algebra in scalar registers (round 4: as per-lane booleans the compiler kept c0..c3 as 0 / 1
+    // words in vector registers -- fifteen more vector instructions per 64 beams in a kernel whose vector pipe is the
+    // busiest unit): one compare per slot writes a mask, the masks combine on the scalar unit, and the selects read them.
+    typedef unsigned long long u64;
+    double best = fmin(s0, s1);
+    if (four) best = fmin(best, fmin(s2, s3));
+    const double lim = best * (1.0 + 1e-15);
+    const u64 m0 = __ballot(s0 <= lim), m1 = __ballot(s1 <= lim);
+    u64 m2 = 0ull, m3 = 0ull;
     if (four) {
-        best = fmin(fmin(s0, s1), fmin(s2, s3));
-        lim = best * (1.0 + 1e-15);
-        c0 = s0 <= lim; c1 = s1 <= lim; c2 = s2 <= lim; c3 = s3 <= lim;
-    } else {
-        best = fmin(s0, s1);
-        lim = best * (1.0 + 1e-15);
-        c0 = s0 <= lim; c1 = s1 <= lim;
+        m2 = __ballot(s2 <= lim);
+        m3 = __ballot(s3 <= lim);
     }
-    const bool tie = (c0 & (c1 | c2 | c3)) | (c1 & (c2 | c3)) | (c2 & c3);
-    const int bid = c0 ? ic.x : (c1 ? ic.y : (c2 ? id2 : id3));
-    int lab = ((c0 | c1 | c2 | c3) & (bid >= 0) & !(best > thr2)) ? bid : -1;   // (no c_i: a non-finite point)
-    if (__builtin_expect((n > kNeighCap) | ((n != 0) & tie), 0)) lab = assoc_grid_walk(g, gp, cx, cy, wx, wy, thr, thr2);
+    const u64 tie = (m0 & (m1 | m2 | m3)) | (m1 & (m2 | m3)) | (m2 & m3);
+    int bid = mask_select(m2, id2, id3);
+    bid = mask_select(m1, ic.y, bid);
+    bid = mask_select(m0, ic.x, bid);
+    const u64 ok = (m0 | m1 | m2 | m3) & __ballot(bid >= 0) & ~__ballot(best > thr2);   // (no m_i: a non-finite point)
+    int lab = mask_select_or_minus1(ok, bid);
+    const u64 walk = __ballot(n > kNeighCap) | (__ballot(n != 0) & tie);
+    if (__builtin_expect(walk != 0ull, 0)) {
+        if ((walk >> lane_id()) & 1ull) lab = assoc_grid_walk(g, gp, cx, cy, wx, wy, thr, thr2);
+    }
     return n == 0 ? -1 : lab;
 }
 
@@ -761,10 +786,10 @@ __device__ __forceinline__ void seg_step(bool take, double& ax, double& ay) {
 // then whatever the register held.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void seg_step_rows(bool take, double& ax, double& ay) {
-    const int xl = __builtin_amdgcn_update_dpp(__double2loint(ax), __double2loint(ax), CTRL, ROW_MASK, 0xF, false);
-    const int xh = __builtin_amdgcn_update_dpp(__double2hiint(ax), __double2hiint(ax), CTRL, ROW_MASK, 0xF, false);
-    const int yl = __builtin_amdgcn_update_dpp(__double2loint(ay), __double2loint(ay), CTRL, ROW_MASK, 0xF, false);
-    const int yh = __builtin_amdgcn_update_dpp(__double2hiint(ay), __double2hiint(ay), CTRL, ROW_MASK, 0xF, false);
+    const int xl = __builtin_amdgcn_mov_dpp(__double2loint(ax), CTRL, ROW_MASK, 0xF, false);
+    const int xh = __builtin_amdgcn_mov_dpp(__double2hiint(ax), CTRL, ROW_MASK, 0xF, false);
+    const int yl = __builtin_amdgcn_mov_dpp(__double2loint(ay), CTRL, ROW_MASK, 0xF, false);
+    const int yh = __builtin_amdgcn_mov_dpp(__double2hiint(ay), CTRL, ROW_MASK, 0xF, false);
     if (take) {
         ax += __hiloint2double(xh, xl);
         ay += __hiloint2double(yh, yl);
@@ -802,7 +827,7 @@ struct PoseTable {
 // poses per wave with the next pose's header and first beams in flight -- 0.192 / 0.202 / 0.217 ms at 1 / 2 / 4 poses per
 // wave; persistent waves striding over the poses -- +19 % .. +51 %; one-wave workgroups -- no difference.)
 template <bool PRELABEL, bool DEBUG, int HS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_ASSOC_WPE : 4, HS == 128 ? 8 : 5)))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? 7 : 4, HS == 128 ? 8 : 5)))
 void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
                                                         int t_begin, int nloc, const int* __restrict__ boff,
                                                         const double2* __restrict__ bxy,
