@@ -1063,8 +1063,8 @@ int icm_sweep_local(icm_handle* h) {
     GridView gv{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p};
     const bool dbg = h->debug || h->per_beam;
     h->assoc_kept = dbg;
-#define ASSOC_ARGS h->x, h->x0.p, (int)h->t_begin, nloc, h->boff.p, h->bxy.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
-        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->fl, h->rot.p, (int)h->nnz, h->st_off.p, h->ent_off.p, 0, (int)h->stl.sparse0
+#define ASSOC_ARGS h->x, h->boff.p, h->bxy.p, h->rot.p, h->gpar.p, h->ent_off.p, nloc, (int)h->t_begin, h->x0.p, gv, h->cfg.dist_thr, h->thr2, h->label.p, \
+        h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->fl, (int)h->nnz, h->st_off.p, 0, (int)h->stl.sparse0
 #define ASSOC_GROUP(PRE, DBG, HS) TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS><<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(ASSOC_ARGS)))
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
     if (!h->rot_valid) {   // (the poses came from the host, a snapshot or a solve form that does not keep the table)
@@ -1218,9 +1218,9 @@ static int launch_ghost(icm_handle* h) {
     }
     int* gm = h->gh_misc.p;   // [0] nent [1] isnew [2] st_off [3..4] reservation plan (zeros) [8..23] the ghost launch's flags
     HIPCHK(h, hipMemsetAsync(gm + 8, 0, 16 * sizeof(int), gs));
-    k_assoc_group<false, false, 256><<<1, kBlock, 0, gs>>>(h->x, h->x0.p, (int)h->t_begin - 1, 1, h->gh_boff.p, h->gh_bxy.p,
+    k_assoc_group<false, false, 256><<<1, kBlock, 0, gs>>>(h->x, h->gh_boff.p, h->gh_bxy.p, h->gh_rot.p, h->gpar.p, gm + 3, 1, (int)h->t_begin - 1, h->x0.p,
         GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p}, h->cfg.dist_thr, h->thr2, h->gh_label.p, h->gh_bloc.p, h->gh_st_label.p,
-        h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p, gm, gm + 1, gm + 8, h->gh_rot.p, h->ghost_n, gm + 2, gm + 3, 0, kWave);
+        h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p, gm, gm + 1, gm + 8, h->ghost_n, gm + 2, 0, kWave);
     k_ghost_moments<<<1, kWave, 0, gs>>>(h->x, (int)h->t_begin - 1, gm, gm + 2, h->gh_st_label.p, h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p,
         h->gh_s2.p, h->gh_rot.p, h->off_sx.p, h->off_sy.p, h->off_n.p,
         h->stats_all + (size_t)(h->rank - 1) * (size_t)icm_stats_stride(h), L, h->lact0, h->gh_m.p, gm + 8, h->fl);
@@ -2408,6 +2408,13 @@ int icm_set_debug(icm_handle* h, int on) {
     return ICM_OK;
 }
 
+#ifdef ICM_ASSOC_TS
+int icm_debug_assoc_ts(icm_handle* h, unsigned long long* out, int n8) {
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(icm::g_assoc_ts), sizeof(unsigned long long) * (size_t)n8));
+    return ICM_OK;
+}
+#endif
 #ifdef ICM_WAVE_TS
 int icm_debug_wave_ts(icm_handle* h, unsigned long long* out, int n4) {
     HIPCHK(h, hipDeviceSynchronize());

@@ -826,18 +826,28 @@ struct PoseTable {
 // One wave per pose, four poses per 256-thread workgroup.  (Measured and dropped, DESIGN.md appendix: several consecutive
 // poses per wave with the next pose's header and first beams in flight -- 0.192 / 0.202 / 0.217 ms at 1 / 2 / 4 poses per
 // wave; persistent waves striding over the poses -- +19 % .. +51 %; one-wave workgroups -- no difference.)
+#ifdef ICM_ASSOC_TS   // measurement builds only (tools/assoc_timeline.py): shader-clock stamps of every 16th pose's wave
+__device__ unsigned long long g_assoc_ts[8 * 8192];
+#define ASSOC_TS(slot) do { if (lane == 0 && (tl & 15) == 0 && (tl >> 4) < 8192) g_assoc_ts[8 * (tl >> 4) + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ASSOC_TS_VAL(slot, v) do { if (lane == 0 && (tl & 15) == 0 && (tl >> 4) < 8192) g_assoc_ts[8 * (tl >> 4) + (slot)] = (unsigned long long)(v); } while (0)
+#else
+#define ASSOC_TS(slot) do { } while (0)
+#define ASSOC_TS_VAL(slot, v) do { } while (0)
+#endif
 template <bool PRELABEL, bool DEBUG, int HS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? 7 : 4, HS == 128 ? 8 : 5)))
-void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
-                                                        int t_begin, int nloc, const int* __restrict__ boff,
-                                                        const double2* __restrict__ bxy,
+void k_assoc_group(const double* __restrict__ x, const int* __restrict__ boff, const double2* __restrict__ bxy,
+                                                        const double* __restrict__ rot, const GridParams* __restrict__ gpar,
+                                                        const int* __restrict__ plan, int nloc, int t_begin,
+                                                        // ^ the fourteen dwords every wave needs at once: they arrive in scalar registers
+                                                        //   with the wave (kernel-argument preload, Makefile), not by a load of its own
+                                                        const double* __restrict__ x0,
                                                         GridView g, double thr, double thr2, int* __restrict__ label,
                                                         int* __restrict__ bloc, int* __restrict__ st_label,
                                                         unsigned short* __restrict__ st_k, double* __restrict__ st_sbx,
                                                         double* __restrict__ st_sby, int* __restrict__ nent_out,
                                                         int* __restrict__ isnew_out, int* __restrict__ flags,
-                                                        const double* __restrict__ rot = nullptr, int nnz_total = 0,
-                                                        int* __restrict__ st_off = nullptr, const int* __restrict__ plan = nullptr,
+                                                        int nnz_total = 0, int* __restrict__ st_off = nullptr,
                                                         int pose0 = 0, int sparse0 = 0) {
     constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
     constexpr int kHashShift = HS == 128 ? 25 : 24;
@@ -845,8 +855,9 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     const int lane = lane_id();
     const int tl = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave_in_block());
     if (tl >= nloc) return;
+    ASSOC_TS(0);
     PoseTable<HS>& T = tables[wave_in_block()];
-    const GridParams gp = *g.par;
+    const GridParams gp = *gpar;   // (= *g.par)
     // (explicit 32-bit byte offsets from a scalar base: a pose has far fewer than 2^29 beams)
     // (a beam's body-frame point is ONE 16-byte load from the interleaved copy the pre-filter leaves beside its two
     // arrays: this kernel's time follows the number of vector loads it issues)
@@ -856,14 +867,12 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     // (wave-uniform values through scalar registers: the pose's beam range becomes a scalar base pointer plus a
     // 32-bit lane offset)
     const int j0 = __builtin_amdgcn_readfirstlane(boff[tl]), j1 = __builtin_amdgcn_readfirstlane(boff[tl + 1]);
-    double px, py, th, ct, st;
+    // this pose's reserved place (scalar loads, in flight while the beams are grouped)
+    const int plan0 = __builtin_amdgcn_readfirstlane(plan[tl]), plan1 = __builtin_amdgcn_readfirstlane(plan[tl + 1]);
+    // (cos, sin)(theta - pi/2) from the sweep's table (k_pose_rot / whoever wrote the pose): computed once per pose and sweep
+    const double ct = rot[2 * (size_t)tl], st = rot[2 * (size_t)tl + 1];
+    double px, py, th;
     pose_of(x, x0, t_begin + tl, px, py, th);
-    if (rot) {   // (cos, sin)(theta - pi/2) from the sweep's table: the same values, computed once
-        ct = rot[2 * (size_t)tl];
-        st = rot[2 * (size_t)tl + 1];
-    } else {
-        pose_rot(th, ct, st);
-    }
     if (j0 == j1) {
         if (lane == 0) {
             nent_out[tl] = 0;
@@ -879,8 +888,6 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         nbx = f.x;
         nby = f.y;
     }
-    // this pose's reserved place (scalar loads, in flight while the beams are grouped)
-    const int plan0 = __builtin_amdgcn_readfirstlane(plan[tl]), plan1 = __builtin_amdgcn_readfirstlane(plan[tl + 1]);
     const double2* __restrict__ bxyp = bxy + j0;
     const unsigned nbeam = (unsigned)(j1 - j0);
     for (int s = lane; s < kHash; s += kWave) {
@@ -892,6 +899,13 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
     int nent = 0;
     bool overflow = false;
     __builtin_amdgcn_wave_barrier();
+#ifdef ICM_ASSOC_TS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ASSOC_TS(1);   // header scalars are in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASSOC_TS(2);   // first beams are in
+    int nbatch = 0;
+#endif
     // body points of the next 64 beams are requested one iteration ahead (unconditional loads at a clamped
     // index, so that the wait in front of their use counts exactly them): a pose's batches no longer pay the
     // latency of this load and of the grid record's one after the other
@@ -983,6 +997,12 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
         }
         if (nent > kGroupCap) overflow = true;
         __builtin_amdgcn_wave_barrier();
+#ifdef ICM_ASSOC_TS
+        ++nbatch;
+        if (nbatch == 1) ASSOC_TS(3);
+        if (nbatch == 2) ASSOC_TS(4);
+        ASSOC_TS(5);
+#endif
     }
     // compact the used slots into the pose's place, slot order: its reserved one if the entries fit, else the front
     // of its own beam range in the sparse area
@@ -1018,6 +1038,10 @@ void k_assoc_group(const double* __restrict__ x, const double* __restrict__ x0,
 
         if (overflow) flags[0] = 1;
     }
+#ifdef ICM_ASSOC_TS
+    ASSOC_TS(6);
+    ASSOC_TS_VAL(7, nbatch);
+#endif
     if (DEBUG) {  // beam -> entry index within the pose
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();

@@ -17,7 +17,7 @@ OUT = os.path.join(ROOT, "scratch", "isa")
 
 def build_isa(defs=()):
     os.makedirs(OUT, exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "--save-temps",
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=14", "--save-temps",
            "-c", os.path.join(ROOT, "icm-slam_amd", "csrc", "icm_api.hip"), "-o", os.path.join(OUT, "api.o")] + ["-D" + d for d in defs]
     subprocess.check_call(cmd, cwd=OUT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return os.path.join(OUT, "icm_api-hip-amdgcn-amd-amdhsa-gfx950.s")
