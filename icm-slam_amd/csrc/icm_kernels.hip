@@ -807,12 +807,12 @@ __device__ __forceinline__ void seg_step_rows(bool take, double& ax, double& ay)
 // (kStageSlack and the sizes of the staging area: staging_layout, icm_host.hpp)
 
 // HS = hash slots per pose; at most 3/4 of them may be used (distinct landmarks of one scan).
-// HS = 128 keeps the kernel at 14 KB of LDS and 64 VGPRs = 8 waves per SIMD (the kernel waits
-// on memory 2/3 of the time, so occupancy matters); a scan that overflows it makes the host
-// relaunch the sweep's phase A with HS = 256.
-#ifndef ICM_ASSOC_WPE
-#define ICM_ASSOC_WPE 8
-#endif
+// HS = 128 keeps the kernel at 14 KB of LDS and under 64 VGPRs; a scan that overflows it makes the host relaunch the
+// sweep's phase A with HS = 256.  Its waves-per-EU attribute is (7, 8), not (8, 8): the compiler's scalar-register
+// budget at eight waves is 80 (800 per SIMD less the trap handler's 16 per wave), which spilled 44 scalars into vector
+// lanes, each read back by a vector instruction in the batch loop; at seven it is 96 -- no spill reads to speak of, and
+// the hardware then keeps seven waves per SIMD resident, which costs nothing: the kernel saturates at about seven
+// (profiles/r04_assoc_occupancy_scaling.txt, r04_assoc_wave_life_experiments.txt).
 
 template <int HS>
 struct PoseTable {
