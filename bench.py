@@ -47,11 +47,12 @@ MAX_SWEEPS_WITHOUT_REWIND = 40   # S2 leaves the association gate after ~50 cons
 RESET_EVERY = 12
 
 
-def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True):
+def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True, runs=0):
     """Compulsory HBM bytes ONE launch of `kernel` moves: every array
     the kernel must read or write once, no re-reads.  nnz = kept beams, E = (pose, landmark)
     entries, nloc = poses of the shard, L = landmark capacity; hier = the hierarchical entry
-    pipeline ran (k_pose_moments then reads the staged entries and the prefixes itself)."""
+    pipeline ran (k_pose_moments then reads the staged entries and the prefixes itself); runs =
+    geometric runs of the kept beams (what k_assoc_runs associates)."""
     ch = 64 if nloc >= 65536 else (32 if nloc >= 16384 else 16)   # poses per chunk (icm_api.hip)
     nchunks = (nloc + ch - 1) // ch
     group = (nchunks + 63) // 64
@@ -65,6 +66,10 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True):
         # read body x,y of every kept beam (16 B) + pose; write one staged entry
         # (label 4, k 2, sum bx 8, sum by 8) per distinct landmark of the scan; counts/flags
         "k_assoc_group": nnz * 16 + E * 22 + nloc * (24 + 8 + 8),
+        # phase A by runs: one 40-B record per run (centre 16, sum of body points 16, radius 4, count | first beam 4) in --
+        # no beam is read where the bounding-circle test settles the run (S2: every run) --, one staged entry (22) per
+        # distinct landmark of the scan out; per pose: pose 24, rotation pair 16, run / beam / plan offsets 12, counts 12
+        "k_assoc_runs": runs * 40 + E * 22 + nloc * (24 + 16 + 12 + 12),
         "k_associate_brute": nnz * (16 + 4) + nloc * 32,
         # staged entries in (22); out: key 4, id 4, k 4, world sums 32, rotated mean offset 16;
         # per pose: pose 24, second moments 24, scatter 24, offsets 8
@@ -391,7 +396,7 @@ def roofline(job, ms_per_step):
     dom = max((k for k in kt if k not in side), key=lambda k: kt[k][0])
 
     def ab_of(k, n_k):
-        return algorithmic_bytes(k, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof, hier)
+        return algorithmic_bytes(k, st["kept_beams"], st["entries"], eng.nloc, eng.L, n_k / nroof, hier, runs=eng.run_counts()[0])
 
     per_kernel = {}
     for k, (ms_k, n_k) in kt.items():
@@ -459,6 +464,17 @@ def roofline(job, ms_per_step):
     roof["sweep_algorithmic_GBps"] = round(sweep_bytes / (ms_per_step * 1e-3) / 1e9, 2)
     roof["sweep_frac_of_hbm_peak"] = round(roof["sweep_algorithmic_GBps"] / (HBM_PEAK_GBS * job.world), 5)
     return roof
+
+
+def _assoc_record(eng):
+    """What phase A associated: the form, the runs of the sequence and how many of them went beam by beam."""
+    if not hasattr(eng, "run_counts"):
+        return None
+    runs, bbb = eng.run_counts()
+    return {"form": "geometric runs of each scan's kept beams, cut once per sequence; a run whose bounding circle settles the argmin and "
+                    "the gate for all its beams takes the label from its centre, the others go beam by beam (same labels as the "
+                    "reference's per-beam rule, scripts/ICM_SLAM_tools.py:168-172)",
+            "runs": runs, "runs_taken_beam_by_beam_so_far": bbb}
 
 
 def dropin_record(job, steps, warmup):
@@ -649,6 +665,7 @@ def run_rank(args):
                    "landmarks": K, "beams": B, "kept_beams": st["kept_beams"] if world == 1 else None,
                    "parallelism": "pose-shard x%d" % world,
                    "entry_pipeline": job.eng.entry_path() if hasattr(job.eng, "entry_path") else None,
+                   "association": _assoc_record(job.eng) if world == 1 else "geometric runs (bounding-circle test, beam by beam where it does not settle)",
                    "fixup_poses": job.eng.fixup_poses() if hasattr(job.eng, "fixup_poses") else None,
                    "state_rewind": ("initial state restored on the device every %d sweeps" % RESET_EVERY) if job.rewind
                    else "none inside a timed window: %d consecutive sweeps from the initial state per window" % (args.steps + args.warmup + 1),

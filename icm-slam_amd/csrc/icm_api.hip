@@ -41,12 +41,12 @@ std::string g_create_err;
 
 enum KernelId {
     KID_PREFILTER = 0, KID_SCAN, KID_ASSOC_BRUTE, KID_ASSOC_GROUP, KID_COMPACT, KID_SORT, KID_LM_BOUNDS, KID_LM_TOTALS,
-    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_FILTRAR, KID_NEIGH, KID_CHUNK_L1, KID_CHUNK_L2, KID_LM_L3, KID_REC_PUSH, KID_POSE_ROT, KID_COUNT
+    KID_STATS_PREFIX, KID_LM_SCAN, KID_BEAM_TARGETS, KID_POSE_MOMENTS, KID_SOLVE, KID_FILTRAR, KID_NEIGH, KID_CHUNK_L1, KID_CHUNK_L2, KID_LM_L3, KID_REC_PUSH, KID_POSE_ROT, KID_ASSOC_RUNS, KID_RUN_BUILD, KID_COUNT
 };
 const char* kKernelNames[KID_COUNT] = {"k_prefilter", "k_scan", "k_associate_brute", "k_assoc_group", "k_compact",
                                        "radix_sort_pairs", "k_lm_bounds", "k_lm_scan_totals", "k_stats_prefix",
                                        "k_lm_scan", "k_beam_targets", "k_pose_moments", "k_solve", "k_filtrar", "k_neigh_table",
-                                       "k_chunk_l1", "k_chunk_l2", "k_lm_l3", "k_rec_push", "k_pose_rot"};
+                                       "k_chunk_l1", "k_chunk_l2", "k_lm_l3", "k_rec_push", "k_pose_rot", "k_assoc_runs", "k_run_build"};
 
 template <class T>
 struct DevBuf {
@@ -89,6 +89,13 @@ struct icm_handle {
     DevBuf<double2> bxy, gh_bxy;   // the kept beams' body points once more, interleaved (k_assoc_group: one load per beam)
     std::vector<int> h_boff;
     int64_t nnz = 0;
+    // geometric runs of the kept beams (k_run_build, once per sequence): what phase A associates (k_assoc_runs)
+    DevBuf<int> nrun, roff, gh_roff;
+    DevBuf<double2> r_c, r_s, gh_rc, gh_rs;   // bounding-circle centre (body frame) | sum of the run's body points
+    DevBuf<uint2> r_m, gh_rm;                 // radius (float bits, rounded up) | beams | first beam's offset in the pose << 16
+    int64_t nruns = 0;
+    int assoc_form = 1;                       // 1 by runs (k_assoc_runs), 0 beam by beam (k_assoc_group): icm_set_assoc_form
+    DevBuf<unsigned long long> run_counts;    // [1] runs that went beam by beam, over the handle's life
 
     // state
     DevBuf<double> x_own, x0;
@@ -625,6 +632,29 @@ static int reserve_map_buffers(icm_handle* h) {
     return ICM_OK;
 }
 
+// Cuts the kept beams of nloc scans into geometric runs (k_run_build: count, exclusive scan, fill).  Thresholds scale
+// with the gate: a new run where consecutive body points are more than 0.35 dist_thr apart or a point is more than
+// 0.5 dist_thr from the run's first one (a trunk's visible arc is one run; a hedge is cut into pieces small enough
+// for the bounding-circle test of k_assoc_runs to settle them).
+static int build_runs(icm_handle* h, const int* boff, const double2* bxy, int nloc, DevBuf<int>& nrun, DevBuf<int>& roff,
+                      DevBuf<double2>& r_c, DevBuf<double2>& r_s, DevBuf<uint2>& r_m, int64_t* nruns_out) {
+    const double thr = h->cfg.dist_thr > 0.0 ? h->cfg.dist_thr : 1.0;
+    const double gap = 0.35 * thr, ext = 0.5 * thr;
+    HIPCHK(h, nrun.reserve((size_t)nloc + 1));
+    HIPCHK(h, roff.reserve((size_t)nloc + 1));
+    TIMED(h, KID_RUN_BUILD, (k_run_build<false><<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(boff, bxy, nloc, gap * gap, ext * ext, nrun.p, nullptr, nullptr, nullptr, nullptr)));
+    k_exscan_i32<<<1, 1024, 0, h->stream>>>(nrun.p, roff.p, nloc);
+    int total = 0;
+    HIPCHK(h, hipMemcpyAsync(&total, roff.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t nr = (size_t)std::max(total, 1);
+    HIPCHK(h, r_c.reserve(nr)); HIPCHK(h, r_s.reserve(nr)); HIPCHK(h, r_m.reserve(nr));
+    TIMED(h, KID_RUN_BUILD, (k_run_build<true><<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(boff, bxy, nloc, gap * gap, ext * ext, nullptr, roff.p, r_c.p, r_s.p, r_m.p)));
+    HIPCHK(h, hipGetLastError());
+    if (nruns_out) *nruns_out = total;
+    return ICM_OK;
+}
+
 int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     if (!h) return ICM_ERR_ARG;
     if (!h->uploaded) FAIL(h, ICM_ERR_ARG, "icm_prefilter: call icm_upload first");
@@ -655,6 +685,13 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->pose_m.reserve(17 * (size_t)nloc));
     HIPCHK(h, h->rot.reserve(2 * (size_t)nloc));
     TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p, h->bxy.p, h->thr2, h->kmask.p)));
+    // the geometric runs of every scan (k_assoc_runs associates runs, not beams): counted, scanned, filled
+    {
+        int rr = build_runs(h, h->boff.p, h->bxy.p, nloc, h->nrun, h->roff, h->r_c, h->r_s, h->r_m, &h->nruns);
+        if (rr) return rr;
+        HIPCHK(h, h->run_counts.reserve(2));
+        HIPCHK(h, hipMemsetAsync(h->run_counts.p, 0, 2 * sizeof(unsigned long long), h->stream));
+    }
     // per-sweep buffers sized by the kept beams
     // staged entries (packed area, sparse area behind it) and the per-entry prefixes that live at the same places
     if (!staging_layout(h->nnz, nloc, h->stl)) FAIL(h, ICM_ERR_CAPACITY, "too many kept beams for 32-bit entry offsets");
@@ -721,6 +758,12 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         HIPCHK(h, hipMemcpyAsync(gb, h->gh_boff.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->ghost_n = gb[1];
+        {
+            DevBuf<int> gnr;   // (the ghost's run count: scratch)
+            int rr = build_runs(h, h->gh_boff.p, h->gh_bxy.p, 1, gnr, h->gh_roff, h->gh_rc, h->gh_rs, h->gh_rm, nullptr);
+            gnr.release();
+            if (rr) return rr;
+        }
     }
     // the hand-off words of the sweep's side launches (k_wait_word / k_lm_l3, k_x_compare): cleared here, in stream order, in
     // front of the synchronisation below -- never beside a launch that polls them (hipMemset on the null stream is not
@@ -1067,6 +1110,12 @@ int icm_sweep_local(icm_handle* h) {
         h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->fl, (int)h->nnz, h->st_off.p, 0, (int)h->stl.sparse0
 #define ASSOC_GROUP(PRE, DBG, HS) TIMED(h, KID_ASSOC_GROUP, (k_assoc_group<PRE, DBG, HS><<<nblocks_waves(nloc), kBlock, 0, h->stream>>>(ASSOC_ARGS)))
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
+    const float thr_margin = (float)(1e-4 * h->cfg.dist_thr), thr_m = (float)h->cfg.dist_thr - thr_margin;
+#define ASSOC_RUNS(DBG, HS) TIMED(h, KID_ASSOC_RUNS, (k_assoc_runs<DBG, HS><<<nblocks_waves(nloc), kBlock, 0, h->stream>>>( \
+        h->x, h->roff.p, h->r_c.p, h->rot.p, h->gpar.p, h->ent_off.p, nloc, (int)h->t_begin, h->x0.p, h->r_s.p, h->r_m.p, h->boff.p, h->bxy.p, gv, \
+        h->cfg.dist_thr, h->thr2, thr_m, thr_margin, h->label.p, h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->fl, \
+        (int)h->nnz, h->st_off.p, 0, (int)h->stl.sparse0, h->run_counts.p)))
+#define ASSOC_RUNS_HS(DBG) do { if (h->hash_slots == 128) ASSOC_RUNS(DBG, 128); else ASSOC_RUNS(DBG, 256); } while (0)
     if (!h->rot_valid) {   // (the poses came from the host, a snapshot or a solve form that does not keep the table)
         TIMED(h, KID_POSE_ROT, (k_pose_rot<<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(h->x, h->x0.p, (int)h->t_begin, nloc, h->rot.p, h->pose_cs.p)));
         h->rot_valid = true;
@@ -1090,6 +1139,8 @@ int icm_sweep_local(icm_handle* h) {
     for (;;) {
         if (h->brute) {
             if (dbg) ASSOC_GROUP_HS(true, true); else ASSOC_GROUP_HS(true, false);
+        } else if (h->assoc_form == 1) {   // by runs: the bounding-circle test, beam by beam where it does not settle
+            if (dbg) ASSOC_RUNS_HS(true); else ASSOC_RUNS_HS(false);
         } else {
             if (dbg) ASSOC_GROUP_HS(false, true); else ASSOC_GROUP_HS(false, false);
         }
@@ -1159,6 +1210,8 @@ int icm_sweep_local(icm_handle* h) {
         }
         break;
     }
+#undef ASSOC_RUNS_HS
+#undef ASSOC_RUNS
 #undef ASSOC_GROUP_HS
 #undef ASSOC_GROUP
 #undef ASSOC_ARGS
@@ -1218,6 +1271,12 @@ static int launch_ghost(icm_handle* h) {
     }
     int* gm = h->gh_misc.p;   // [0] nent [1] isnew [2] st_off [3..4] reservation plan (zeros) [8..23] the ghost launch's flags
     HIPCHK(h, hipMemsetAsync(gm + 8, 0, 16 * sizeof(int), gs));
+    if (h->assoc_form == 1) {   // (the form its owner's rank uses: the ghost's entries carry the owner's sums bit for bit)
+        const float thr_margin = (float)(1e-4 * h->cfg.dist_thr), thr_m = (float)h->cfg.dist_thr - thr_margin;
+        k_assoc_runs<false, 256><<<1, kBlock, 0, gs>>>(h->x, h->gh_roff.p, h->gh_rc.p, h->gh_rot.p, h->gpar.p, gm + 3, 1, (int)h->t_begin - 1, h->x0.p,
+            h->gh_rs.p, h->gh_rm.p, h->gh_boff.p, h->gh_bxy.p, GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p}, h->cfg.dist_thr, h->thr2, thr_m, thr_margin,
+            h->gh_label.p, h->gh_bloc.p, h->gh_st_label.p, h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p, gm, gm + 1, gm + 8, h->ghost_n, gm + 2, 0, kWave, nullptr);
+    } else
     k_assoc_group<false, false, 256><<<1, kBlock, 0, gs>>>(h->x, h->gh_boff.p, h->gh_bxy.p, h->gh_rot.p, h->gpar.p, gm + 3, 1, (int)h->t_begin - 1, h->x0.p,
         GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p}, h->cfg.dist_thr, h->thr2, h->gh_label.p, h->gh_bloc.p, h->gh_st_label.p,
         h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p, gm, gm + 1, gm + 8, h->ghost_n, gm + 2, 0, kWave);
@@ -2565,6 +2624,51 @@ int icm_set_gpu_filtrar(icm_handle* h, int on) {
 }
 
 // test hook: switch phase A to the brute-force (all landmarks, LDS-tiled) kernel
+int icm_set_assoc_form(icm_handle* h, int form) {
+    if (!h || (form != 0 && form != 1)) return ICM_ERR_ARG;
+    h->assoc_form = form;
+    return ICM_OK;
+}
+
+int icm_get_run_counts(icm_handle* h, int64_t* out2) {
+    if (!h || !out2) return ICM_ERR_ARG;
+    if (!h->prefiltered) FAIL(h, ICM_ERR_ARG, "icm_get_run_counts: call icm_prefilter first");
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long c[2] = {0, 0};
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(c, h->run_counts.p, sizeof(c), hipMemcpyDeviceToHost));
+    out2[0] = h->nruns;
+    out2[1] = (int64_t)c[1];
+    return ICM_OK;
+}
+
+int icm_get_runs(icm_handle* h, int64_t* offsets, double* centre_xy, double* sum_xy, float* radius, int32_t* count, int32_t* first) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->prefiltered) FAIL(h, ICM_ERR_ARG, "icm_get_runs: call icm_prefilter first");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t nloc = (size_t)h->nloc, nr = (size_t)h->nruns;
+    if (offsets) {
+        std::vector<int> ro(nloc + 1);
+        HIPCHK(h, hipMemcpy(ro.data(), h->roff.p, (nloc + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i <= nloc; ++i) offsets[i] = ro[i];
+    }
+    if (nr) {
+        if (centre_xy) HIPCHK(h, hipMemcpy(centre_xy, h->r_c.p, nr * sizeof(double2), hipMemcpyDeviceToHost));
+        if (sum_xy) HIPCHK(h, hipMemcpy(sum_xy, h->r_s.p, nr * sizeof(double2), hipMemcpyDeviceToHost));
+        if (radius || count || first) {
+            std::vector<uint2> m(nr);
+            HIPCHK(h, hipMemcpy(m.data(), h->r_m.p, nr * sizeof(uint2), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nr; ++i) {
+                if (radius) std::memcpy(&radius[i], &m[i].x, sizeof(float));
+                if (count) count[i] = (int32_t)(m[i].y & 0xffffu);
+                if (first) first[i] = (int32_t)(m[i].y >> 16);
+            }
+        }
+    }
+    return ICM_OK;
+}
+
 int icm_set_brute_force(icm_handle* h, int on) {
     if (!h) return ICM_ERR_ARG;
     h->brute = on != 0;

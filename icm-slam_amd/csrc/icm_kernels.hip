@@ -1049,6 +1049,316 @@ void k_assoc_group(const double* __restrict__ x, const int* __restrict__ boff, c
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Phase A by RUNS (round 5).  The cdist / argmin / gate of Mapa.actualizar (reference scripts/ICM_SLAM_tools.py:168-172)
+// is a per-beam rule, but its outcome is almost always the same for every beam of a small cluster of neighbouring
+// returns (one trunk): 6.3 beams share a label on S2.  A geometric RUN is a stretch of consecutive kept beams of one
+// scan whose body-frame points lie close together -- a function of the scan alone, so it is cut ONCE per sequence, beside
+// filtrar_z (k_run_build), with its bounding circle (centre c, radius r), beam count k and sum of body points.  Per
+// sweep ONE lane per run projects the centre with the pose's previous-sweep value (tras_rot_z, :465-480, is a rigid
+// motion: every beam's world point stays within r of the centre's), reads ONE grid record and takes the nearest
+// candidate i1 at distance d1 and the second nearest at d2.  With cell >= dist_thr the edge of the search grid:
+//     d1 + r <= dist_thr            every beam is inside the gate of i1            (|w_j - y_i1| <= d1 + r)
+//     d2 - r >  d1 + r              every other candidate of the record is farther from every beam than i1
+//     d1 + 2r < cell                every landmark outside the record's 3x3 cells is farther than cell - r > d1 + r
+// (each with a margin of 1e-4 dist_thr, five orders of magnitude above the rounding of a projected point) => argmin and
+// gate of EVERY beam of the run are i1, exactly as the reference decides beam by beam, ties impossible.  A run the test
+// does not settle (crowded or distant landmarks, gated-out beams, more than four candidates) goes beam by beam through
+// assoc_grid, the rule of k_assoc_group.  A settled run then IS a partial entry: its cached (k, sum b) are added to the
+// pose's label table -- no beam is read in the common case.  S2: 3.7 M lanes and grid records instead of 23.0 M.
+// ---------------------------------------------------------------------------------------
+constexpr int kRunCap = 64;        // beams per run at most (an unsettled run is one batch of the beam-by-beam path)
+constexpr int kRunUndecided = -3;
+
+// One thread per pose cuts its kept beams into runs: a new run starts where the next body point is farther than `gap`
+// from the last one, farther than `ext` from the run's first point, or after kRunCap beams.  FILL = false counts the
+// runs (nrun), FILL = true writes them at roff[t]: centre = mean of the body points, radius = largest distance to it
+// rounded UP into a float, k | first beam's offset within the pose << 16, sum of the body points in beam order.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_run_build(const int* __restrict__ boff, const double2* __restrict__ bxy, int nloc,
+                                                      double gap2, double ext2, int* __restrict__ nrun,
+                                                      const int* __restrict__ roff, double2* __restrict__ r_c,
+                                                      double2* __restrict__ r_s, uint2* __restrict__ r_m) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= nloc) return;
+    const int j0 = boff[t], j1 = boff[t + 1];
+    int n = 0, o = FILL ? roff[t] : 0;
+    int js = j0;   // first beam of the open run
+    double fx = 0.0, fy = 0.0, lx = 0.0, ly = 0.0, sx = 0.0, sy = 0.0;
+    for (int j = j0; j <= j1; ++j) {
+        bool cut = j == j1;
+        double bx = 0.0, by = 0.0;
+        if (!cut) {
+            const double2 b = bxy[j];
+            bx = b.x; by = b.y;
+            if (j > js) {
+                const double gx = bx - lx, gy = by - ly, ex = bx - fx, ey = by - fy;
+                cut = gx * gx + gy * gy > gap2 || ex * ex + ey * ey > ext2 || j - js >= kRunCap;
+            }
+        }
+        if (cut && j > js) {   // close [js, j)
+            if (FILL) {
+                const int k = j - js;
+                const double cx = sx / (double)k, cy = sy / (double)k;
+                double r2 = 0.0;
+                for (int i = js; i < j; ++i) {
+                    const double2 q = bxy[i];
+                    const double dx = q.x - cx, dy = q.y - cy;
+                    r2 = fmax(r2, dx * dx + dy * dy);
+                }
+                const float rf = __double2float_ru(sqrt(r2) * 1.000001 + 1e-12);
+                r_c[o] = make_double2(cx, cy);
+                r_s[o] = make_double2(sx, sy);
+                r_m[o] = make_uint2(__float_as_uint(rf), (unsigned)k | ((unsigned)(js - j0) << 16));
+                ++o;
+            }
+            ++n;
+            js = j;
+        }
+        if (j < j1) {
+            if (j == js) {
+                fx = bx; fy = by;
+                sx = bx; sy = by;
+            } else {
+                sx += bx; sy += by;
+            }
+            lx = bx; ly = by;
+        }
+    }
+    if (!FILL) nrun[t] = n;
+}
+
+// The run's decision from the record of its centre's cell (see the header above).  Returns the label every beam of the
+// run takes, or kRunUndecided.  thr_m = dist_thr - margin, eps = the margin, all in single precision: the squared
+// distances are formed in double from the double world point (a map may lie kilometres from its origin), only their
+// square roots and the three comparisons are single (relative error 1e-7 of a value of a few dist_thr << margin).
+__device__ __forceinline__ int assoc_run(const GridView& g, const GridParams& gp, double wx, double wy, float r, float thr_m,
+                                         float eps, float invf) {
+    const int cx = grid_cell(wx, gp.gx0, gp.inv, gp.nx), cy = grid_cell(wy, gp.gy0, gp.inv, gp.ny);
+    const unsigned off = ((unsigned)cy * (unsigned)gp.nx + (unsigned)cx) << 7;
+    const char* __restrict__ rec = reinterpret_cast<const char*>(g.nb) + off;
+    const double2 p0 = *reinterpret_cast<const double2*>(rec), p1 = *reinterpret_cast<const double2*>(rec + 16);
+    const int4 ic = *reinterpret_cast<const int4*>(rec + 32);   // id0, id1, n, id2
+    const int n = ic.z;
+    double dx = p0.x - wx, dy = p0.y - wy;
+    const double s0 = dx * dx + dy * dy;
+    dx = p1.x - wx; dy = p1.y - wy;
+    const double s1 = dx * dx + dy * dy;
+    // nearest and second nearest of the (up to four) candidates; empty slots hold x = +inf
+    double best = fmin(s0, s1), second = fmax(s0, s1);
+    int bid = s1 < s0 ? ic.y : ic.x;
+    if (__builtin_expect(__ballot(n > 2) != 0ull, 0)) {
+        if (n > 2) {
+            const double2 q2 = *reinterpret_cast<const double2*>(rec + 48), q3 = *reinterpret_cast<const double2*>(rec + 64);
+            const int id3 = *reinterpret_cast<const int*>(rec + 80);
+            dx = q2.x - wx; dy = q2.y - wy;
+            const double s2 = dx * dx + dy * dy;
+            dx = q3.x - wx; dy = q3.y - wy;
+            const double s3 = dx * dx + dy * dy;
+            const double lo = fmin(s2, s3), hi = fmax(s2, s3);
+            const int lid = s3 < s2 ? id3 : ic.w;
+            second = fmin(fmax(best, lo), fmin(second, hi));
+            if (lo < best) bid = lid;
+            best = fmin(best, lo);
+        }
+    }
+    const float d1 = __builtin_amdgcn_sqrtf((float)best), d2 = __builtin_amdgcn_sqrtf((float)second);
+    const float r2 = r + r;
+    const bool settled = (n >= 1) & (n <= kNeighCap) & (d1 + r <= thr_m) & ((d1 + r2) * invf <= 1.0f - 1e-4f) & (d2 - d1 >= r2 + eps) & (bid >= 0);
+    return settled ? bid : kRunUndecided;
+}
+
+// One wave per pose, lanes over its RUNS.  Same outputs as k_assoc_group (the pose's entries, one per distinct label, in
+// the order of the label table's slots, staged at the pose's reserved place): everything behind phase A is unchanged.
+template <bool DEBUG, int HS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? 7 : 4, HS == 128 ? 8 : 5)))
+void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, const double2* __restrict__ r_c,
+                  const double* __restrict__ rot, const GridParams* __restrict__ gpar, const int* __restrict__ plan, int nloc, int t_begin,
+                  // ^ the fourteen dwords that arrive in scalar registers with the wave (kernel-argument preload)
+                  const double* __restrict__ x0, const double2* __restrict__ r_s, const uint2* __restrict__ r_m,
+                  const int* __restrict__ boff, const double2* __restrict__ bxy, GridView g, double thr, double thr2,
+                  float thr_m, float eps, int* __restrict__ label, int* __restrict__ bloc, int* __restrict__ st_label,
+                  unsigned short* __restrict__ st_k, double* __restrict__ st_sbx, double* __restrict__ st_sby,
+                  int* __restrict__ nent_out, int* __restrict__ isnew_out, int* __restrict__ flags, int nnz_total,
+                  int* __restrict__ st_off, int pose0, int sparse0, unsigned long long* __restrict__ run_counts) {
+    constexpr int kHash = HS, kGroupCap = HS * 3 / 4;
+    constexpr int kHashShift = HS == 128 ? 25 : 24;
+    __shared__ PoseTable<HS> tables[kWavesPerBlock];
+    const int lane = lane_id();
+    const int tl = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave_in_block());
+    if (tl >= nloc) return;
+    PoseTable<HS>& T = tables[wave_in_block()];
+    const GridParams gp = *gpar;
+    const int R0 = __builtin_amdgcn_readfirstlane(roff[tl]), R1 = __builtin_amdgcn_readfirstlane(roff[tl + 1]);
+    const int plan0 = __builtin_amdgcn_readfirstlane(plan[tl]), plan1 = __builtin_amdgcn_readfirstlane(plan[tl + 1]);
+    const int j0 = __builtin_amdgcn_readfirstlane(boff[tl]);   // (first kept beam: the sparse staging place, the beam-by-beam path)
+    const double ct = rot[2 * (size_t)tl], st = rot[2 * (size_t)tl + 1];
+    double px, py, th;
+    pose_of(x, x0, t_begin + tl, px, py, th);
+    if (R0 == R1) {   // no kept beams
+        if (lane == 0) {
+            nent_out[tl] = 0;
+            isnew_out[tl] = 0;
+            st_off[tl] = 0;
+        }
+        return;
+    }
+    const unsigned nrun = (unsigned)(R1 - R0);
+    auto at16 = [](const double2* __restrict__ base, unsigned idx) {
+        return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + (idx << 4));
+    };
+    const double2* __restrict__ rcp = r_c + R0;
+    const double2* __restrict__ rsp = r_s + R0;
+    const uint2* __restrict__ rmp = r_m + R0;
+    // the pose's first 64 runs (lanes beyond the last run hold a copy of it and take no part)
+    double2 c, sb;
+    uint2 m;
+    {
+        const unsigned i0 = min((unsigned)lane, nrun - 1u);
+        c = at16(rcp, i0);
+        sb = at16(rsp, i0);
+        m = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rmp) + (i0 << 3));
+    }
+    for (int s = lane; s < kHash; s += kWave) {
+        T.key[s] = kEmpty;
+        T.cnt[s] = 0;
+        T.sx[s] = 0.0;
+        T.sy[s] = 0.0;
+    }
+    const float invf = (float)gp.inv;
+    int nent = 0;
+    bool overflow = false;
+    unsigned n_und = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (unsigned base = 0; base < nrun && !overflow; base += kWave) {
+        const bool valid = base + (unsigned)lane < nrun;
+        const int k = (int)(m.y & 0xffffu);
+        const int jr = j0 + (int)(m.y >> 16);
+        int lab = kRunUndecided;
+        if (valid) {
+            const double wx = (c.x * ct - c.y * st) + px;
+            const double wy = (c.x * st + c.y * ct) + py;
+            lab = assoc_run(g, gp, wx, wy, __uint_as_float(m.x), thr_m, eps, invf);
+        }
+        const bool settled = valid && lab != kRunUndecided;
+        // settled runs claim / find the slot of their label (linear probing; a probe IS the compare-and-swap) and add
+        // their cached totals by LDS atomics -- two runs of one landmark (seen left and right of an occluder, or
+        // across the scan's wrap-around) need no arbitration
+        int slot = (int)(((unsigned)lab * 2654435761u) >> kHashShift);
+        bool inserted = false, found = false;
+        if (settled) {
+            int held = atomicCAS(&T.key[slot], kEmpty, lab);
+            for (int probes = 0; probes < kHash; ++probes) {
+                if (held == kEmpty || held == lab) {
+                    inserted = held == kEmpty;
+                    found = true;
+                    break;
+                }
+                slot = (slot + 1) & (kHash - 1);
+                held = atomicCAS(&T.key[slot], kEmpty, lab);
+            }
+        }
+        if (__ballot(settled && !found) != 0ull) overflow = true;
+        nent += __popcll(__ballot(inserted));
+        if (settled && found) {
+            atomicAdd(&T.cnt[slot], k);
+            lds_add_f64(&T.sx[slot], sb.x);
+            lds_add_f64(&T.sy[slot], sb.y);
+        }
+        if (DEBUG && settled) {
+            for (int i = 0; i < k; ++i) {
+                label[jr + i] = lab;
+                bloc[jr + i] = slot;
+            }
+        }
+        // the runs the test did not settle: beam by beam, the reference's rule literally (assoc_grid), one run at a time
+        unsigned long long und = __ballot(valid && !settled);
+        n_und += (unsigned)__popcll(und);
+        while (und != 0ull && !overflow) {
+            const int l = (int)__builtin_ctzll(und);
+            und &= und - 1ull;
+            const int kk = lane_bcast(k, l), jj = lane_bcast(jr, l);
+            const bool on = lane < kk;
+            int bl = -2, bs = 0;
+            bool bins = false, bfound = false;
+            if (on) {
+                const double2 b = bxy[jj + lane];
+                const double wx = (b.x * ct - b.y * st) + px;
+                const double wy = (b.x * st + b.y * ct) + py;
+                bl = assoc_grid(g, gp, wx, wy, thr, thr2);
+                bs = (int)(((unsigned)bl * 2654435761u) >> kHashShift);
+                int held = atomicCAS(&T.key[bs], kEmpty, bl);
+                for (int probes = 0; probes < kHash; ++probes) {
+                    if (held == kEmpty || held == bl) {
+                        bins = held == kEmpty;
+                        bfound = true;
+                        break;
+                    }
+                    bs = (bs + 1) & (kHash - 1);
+                    held = atomicCAS(&T.key[bs], kEmpty, bl);
+                }
+                if (bfound) {
+                    atomicAdd(&T.cnt[bs], 1);
+                    lds_add_f64(&T.sx[bs], b.x);
+                    lds_add_f64(&T.sy[bs], b.y);
+                }
+                if (DEBUG) {
+                    label[jj + lane] = bl;
+                    bloc[jj + lane] = bs;
+                }
+            }
+            if (__ballot(on && !bfound) != 0ull) overflow = true;
+            nent += __popcll(__ballot(bins));
+            if (nent > kGroupCap) overflow = true;
+        }
+        if (nent > kGroupCap) overflow = true;
+        if (base + kWave < nrun) {   // (a scan with more than 64 runs)
+            const unsigned in = min(base + (unsigned)kWave + (unsigned)lane, nrun - 1u);
+            c = at16(rcp, in);
+            sb = at16(rsp, in);
+            m = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rmp) + (in << 3));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // compact the used slots into the pose's place, slot order (as k_assoc_group does)
+    const int room = (plan1 - plan0) + kStageSlack;
+    const bool fits = plan0 >= 0 && plan1 >= plan0 && plan1 <= nnz_total && nent <= room;
+    const int sbase = fits ? plan0 + kStageSlack * (pose0 + tl) : sparse0 + j0;
+    int written = 0;
+    bool isnew = false;
+    for (int s0 = 0; s0 < kHash; s0 += kWave) {
+        const int s = s0 + lane;
+        const int key = T.key[s];
+        const bool occ = key != kEmpty;
+        const unsigned long long mask = __ballot(occ);
+        if (occ) {
+            const unsigned q = (unsigned)(written + prefix_count(mask, lane));
+            *reinterpret_cast<int*>(reinterpret_cast<char*>(st_label + sbase) + (q << 2)) = key;
+            *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(st_k + sbase) + (q << 1)) = (unsigned short)T.cnt[s];
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sbx + sbase) + (q << 3)) = T.sx[s];
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sby + sbase) + (q << 3)) = T.sy[s];
+            isnew |= key == -1;
+            if (DEBUG) T.owner[s] = q;
+        }
+        written += __popcll(mask);
+    }
+    const unsigned long long anynew = __ballot(isnew);
+    if (lane == 0) {
+        nent_out[tl] = written;
+        st_off[tl] = sbase;
+        isnew_out[tl] = anynew != 0ull;
+        if (!fits && plan1 > 0) atomicAdd(&flags[3], 1);
+        if (overflow) flags[0] = 1;
+        if (run_counts && n_und) atomicAdd(&run_counts[1], (unsigned long long)n_und);   // (runs that went beam by beam: rare, counted over the handle's life)
+    }
+    if (DEBUG) {  // beam -> entry index within the pose
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int j1 = boff[tl + 1];
+        for (int j = j0 + lane; j < j1; j += kWave) bloc[j] = T.owner[bloc[j]];
+    }
+}
+
 // Running-mean term of one entry: sum of its beams' world points and their count.  One
 // 32-byte record so that the per-landmark gather touches one line per entry.
 struct EntW {

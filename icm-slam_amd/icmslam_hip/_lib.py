@@ -89,6 +89,9 @@ SIGNATURES = {
     "icm_kernel_time": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), _dp, _lp]),
     "icm_last_stats": (C.c_int, [_H, _lp]),
     "icm_set_brute_force": (C.c_int, [_H, C.c_int]),
+    "icm_set_assoc_form": (C.c_int, [_H, C.c_int]),
+    "icm_get_run_counts": (C.c_int, [_H, _lp]),
+    "icm_get_runs": (C.c_int, [_H, _lp, _dp, _dp, C.POINTER(C.c_float), _ip, _ip]),
     "icm_set_debug": (C.c_int, [_H, C.c_int]),
     "icm_get_solve_diag": (C.c_int, [_H, _dp]),
     "icm_set_gpu_filtrar": (C.c_int, [_H, C.c_int]),

@@ -575,6 +575,29 @@ class SweepEngine:
     def set_brute_force(self, on):
         self._chk(self.lib.icm_set_brute_force(self.h, int(bool(on))))
 
+    def set_assoc_form(self, form):
+        """What phase A associates: 1 / 'runs' (default) geometric runs of each scan's kept beams, settled by the
+        bounding-circle test, beam by beam where it does not settle; 0 / 'beams' every kept beam on its own."""
+        form = {"runs": 1, "beams": 0}.get(form, form)
+        self._chk(self.lib.icm_set_assoc_form(self.h, int(form)))
+
+    def runs(self):
+        """The geometric runs of the shard's kept beams: (offsets by pose (nloc+1), centre (n,2), sum of body points (n,2),
+        radius (n) float32, beams (n), first beam's offset among the pose's kept beams (n))."""
+        n = self.run_counts()[0]
+        off = np.zeros(self.nloc + 1, dtype=np.int64)
+        c, sb = np.zeros((max(n, 1), 2)), np.zeros((max(n, 1), 2))
+        r = np.zeros(max(n, 1), dtype=np.float32)
+        k, f = np.zeros(max(n, 1), dtype=np.int32), np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self.lib.icm_get_runs(self.h, lptr(off), dptr(c), dptr(sb), r.ctypes.data_as(C.POINTER(C.c_float)), iptr(k), iptr(f)))
+        return off, c[:n], sb[:n], r[:n], k[:n], f[:n]
+
+    def run_counts(self):
+        """(runs of the uploaded shard, runs that went beam by beam so far)."""
+        a = np.zeros(2, dtype=np.int64)
+        self._chk(self.lib.icm_get_run_counts(self.h, lptr(a)))
+        return int(a[0]), int(a[1])
+
     def enable_timing(self, on=True):
         self._chk(self.lib.icm_enable_timing(self.h, int(bool(on))))
         self._chk(self.lib.icm_reset_timing(self.h))

@@ -18,6 +18,22 @@ extern "C" {
  * mapa_viejo, table tiled through LDS) instead of the grid search.  Same results. */
 int icm_set_brute_force(icm_handle *h, int on);
 
+/* What phase A associates (Mapa.actualizar's cdist / argmin / gate, scripts/ICM_SLAM_tools.py:168-172):
+ *   1 (default) geometric RUNS of each scan's kept beams -- clusters of neighbouring returns cut once per sequence, beside
+ *               filtrar_z, each with its bounding circle: one lane per run settles the label of all its beams from the
+ *               circle's centre when the nearest landmark wins by more than the circle's diameter (exact: see
+ *               k_assoc_runs), and only the runs this does not settle go beam by beam;
+ *   0           every kept beam on its own (k_assoc_group): the cross-check form.
+ * Labels and counts are identical; the per-entry sums of body points are added up in a different order (~1e-16 relative).
+ * icm_get_run_counts: out2 = [0] runs of the uploaded shard, [1] runs that went beam by beam so far, over the handle's
+ * life (synchronises the stream). */
+int icm_set_assoc_form(icm_handle *h, int form);
+int icm_get_run_counts(icm_handle *h, int64_t *out2);
+/* The runs themselves (tests): offsets[nloc + 1] by pose, then per run its bounding circle's centre (x, y interleaved, body
+ * frame), the sum of its beams' body points (interleaved), the radius (rounded up), its beam count and the offset of its
+ * first beam among the pose's kept beams.  Sized by icm_get_run_counts()[0]; any pointer may be NULL. */
+int icm_get_runs(icm_handle *h, int64_t *offsets, double *centre_xy, double *sum_xy, float *radius, int32_t *count, int32_t *first);
+
 /* Keep the per-beam outputs of a sweep (label and running-mean target of every kept beam)
  * for icm_get_association; off by default (they cost 28 B of HBM traffic per kept beam). */
 int icm_set_debug(icm_handle *h, int on);

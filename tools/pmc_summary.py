@@ -5,7 +5,7 @@ usage: pmc_summary.py out.csv dir1 dir2 ...
               (2 x FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950"""
 import csv, glob, os, sys, re, json
 
-BENCH_NAMES = (("k_assoc_group<false, false", "k_assoc_group"), ("k_chunk_l1", "k_chunk_l1"), ("k_chunk_l2", "k_chunk_l2"),
+BENCH_NAMES = (("k_assoc_runs<false", "k_assoc_runs"), ("k_assoc_group<false, false", "k_assoc_group"), ("k_chunk_l1", "k_chunk_l1"), ("k_chunk_l2", "k_chunk_l2"),
                ("k_lm_l3", "k_lm_l3"), ("k_rec_push", "k_rec_push"), ("k_pose_moments", "k_pose_moments"),
                ("k_solve_m_fused", "k_solve"), ("k_scan_", "k_scan"),
                ("k_neigh_table", "k_neigh_table"), ("k_fl_", "k_filtrar"), ("k_pose_rot", "k_pose_rot"))
