@@ -504,6 +504,48 @@ def dropin_record(job, steps, warmup):
             "ms_per_step": round(1e3 * el / steps, 4), "value": round((job.T - 1) * steps / el, 1), "unit": "pose-updates/s"}
 
 
+def dataset_cpu_baseline_c(icm, init):
+    """The compiled C oracle (oracle/icm_oracle_c.c, gcc -O2, ONE thread) on data_IJAC2018 on THIS box's host: the
+    initialisation pass, one sweep in the reference's order and one red-black sweep -- what the same work costs on a
+    CPU core without the Python interpreter, beside the GPU's numbers for the same three jobs."""
+    from oracle import c_oracle as co
+    from oracle import icm_oracle as o
+    cfg = icm.config
+    zz, odo, u = icm.mediciones, icm.odometria, icm.u
+    T = zz.shape[1]
+    kept = co.prefilter(cfg, zz)
+    co.set_threads(1)
+    co.set_grid(False)   # (11 landmarks: the literal scan over all of them, like the reference)
+
+    def med3(f):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[1]
+
+    rec = {"cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+           "what": "compiled C oracle, one thread, literal brute-force association and per-beam energy, SciPy's Nelder-Mead restated; median of 3"}
+    lact = int(init["landmarks_actuales"])
+    for sched in ("sequential", "redblack"):
+        def one():
+            x = np.ascontiguousarray(init["x_init"]).copy()
+            co.sweep(cfg, kept, u, odo, odo[:, 0], init["map_init"], x, lact, sched)
+        t = med3(one)
+        rec[sched] = {"ms": round(1e3 * t, 3), "pose_updates_per_s": round((T - 1) / t, 1)}
+    # the init pass from the first scan's clusters (their SciPy linkage is host work on both sides: not timed here)
+    ocfg = o.OracleConfig.from_config(cfg)
+    st = o.MapState(ocfg)
+    k0 = o.filtrar_z(zz[:, 0], ocfg)
+    y0, _ = o.cluster_first_scan(st, np.zeros((2, ocfg.L)), o.project_beams(odo[:, 0].copy(), k0[:, 2:4]))
+    t = med3(lambda: co.init_pass(cfg, kept, u, odo, y0, st.cant_obs_i, st.landmarks_actuales))
+    rec["init_pass"] = {"ms": round(1e3 * t, 3)}
+    co.set_grid(True)
+    co.set_threads(0)
+    return rec
+
+
 def dataset_record(device):
     """data_IJAC2018 (BASELINE.json configs[0] / [1]: 1833 poses x 181 beams, config_default.yaml) -- the ONE input the real
     reference was ever timed on (in the build container; its Python never travels to the GPU box):
@@ -572,6 +614,11 @@ def dataset_record(device):
                          "build container on ONE core of an 8-core Intel Xeon @ 2.10 GHz, NumPy 2.2.6 / SciPy 1.15.3; not a number "
                          "published by the reference and not measured on this box"}
     out["reference_measured"] = ref
+    out["cpu_baseline_c"] = dataset_cpu_baseline_c(icm, init)
+    cb = out["cpu_baseline_c"]
+    out["gpu_over_cpu_c_one_core"] = {"sweep_sequential": round(cb["sequential"]["ms"] / out["sequential"]["ms"], 2),
+                                      "sweep_redblack": round(cb["redblack"]["ms"] / out["redblack"]["ms"], 1),
+                                      "init_pass": round(cb["init_pass"]["ms"] / out["init_pass"]["ms"], 2)}
     out["speedup_vs_reference_measured"] = {
         "sweep_sequential": [round(ref["sweep_s"][0] / (out["sequential"]["ms"] * 1e-3), 0), round(ref["sweep_s"][1] / (out["sequential"]["ms"] * 1e-3), 0)],
         "sweep_redblack": [round(ref["sweep_s"][0] / (out["redblack"]["ms"] * 1e-3), 0), round(ref["sweep_s"][1] / (out["redblack"]["ms"] * 1e-3), 0)],

@@ -1170,8 +1170,11 @@ __device__ __forceinline__ int assoc_run(const GridView& g, const GridParams& gp
 
 // One wave per pose, lanes over its RUNS.  Same outputs as k_assoc_group (the pose's entries, one per distinct label, in
 // the order of the label table's slots, staged at the pose's reserved place): everything behind phase A is unchanged.
+#ifndef ICM_RUNS_WPE
+#define ICM_RUNS_WPE 7
+#endif
 template <bool DEBUG, int HS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? 7 : 4, HS == 128 ? 8 : 5)))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_RUNS_WPE : 4, HS == 128 ? 8 : 5)))
 void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, const double2* __restrict__ r_c,
                   const double* __restrict__ rot, const GridParams* __restrict__ gpar, const int* __restrict__ plan, int nloc, int t_begin,
                   // ^ the fourteen dwords that arrive in scalar registers with the wave (kernel-argument preload)
@@ -1185,8 +1188,17 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
     constexpr int kHashShift = HS == 128 ? 25 : 24;
     __shared__ PoseTable<HS> tables[kWavesPerBlock];
     const int lane = lane_id();
+#ifdef ICM_EXP_XCD
+    // blocks b, b + 8, b + 16 ... run on one XCD (round-robin dispatch): give each XCD a contiguous range of poses
+    const int nbk = gridDim.x, per = (nbk + 7) >> 3;
+    const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (bid >= nbk) return;
+    const int tl = __builtin_amdgcn_readfirstlane(bid * kWavesPerBlock + wave_in_block());
+#else
     const int tl = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave_in_block());
+#endif
     if (tl >= nloc) return;
+    ASSOC_TS(0);
     PoseTable<HS>& T = tables[wave_in_block()];
     const GridParams gp = *gpar;
     const int R0 = __builtin_amdgcn_readfirstlane(roff[tl]), R1 = __builtin_amdgcn_readfirstlane(roff[tl + 1]);
@@ -1216,7 +1228,11 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
     {
         const unsigned i0 = min((unsigned)lane, nrun - 1u);
         c = at16(rcp, i0);
+#ifndef ICM_EXP_NOSB
         sb = at16(rsp, i0);
+#else
+        sb = c;
+#endif
         m = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rmp) + (i0 << 3));
     }
     for (int s = lane; s < kHash; s += kWave) {
@@ -1230,6 +1246,13 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
     bool overflow = false;
     unsigned n_und = 0;
     __builtin_amdgcn_wave_barrier();
+#ifdef ICM_ASSOC_TS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ASSOC_TS(1);   // header scalars are in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASSOC_TS(2);   // the first runs' records are in
+    int nbatch = 0;
+#endif
     for (unsigned base = 0; base < nrun && !overflow; base += kWave) {
         const bool valid = base + (unsigned)lane < nrun;
         const int k = (int)(m.y & 0xffffu);
@@ -1241,6 +1264,9 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
             lab = assoc_run(g, gp, wx, wy, __uint_as_float(m.x), thr_m, eps, invf);
         }
         const bool settled = valid && lab != kRunUndecided;
+#ifdef ICM_ASSOC_TS
+        if (nbatch == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ASSOC_TS(3); }   // grid records in, decisions made
+#endif
         // settled runs claim / find the slot of their label (linear probing; a probe IS the compare-and-swap) and add
         // their cached totals by LDS atomics -- two runs of one landmark (seen left and right of an occluder, or
         // across the scan's wrap-around) need no arbitration
@@ -1319,6 +1345,11 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
             m = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rmp) + (in << 3));
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef ICM_ASSOC_TS
+        ++nbatch;
+        if (nbatch == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ASSOC_TS(4); }   // table updated
+        ASSOC_TS(5);
+#endif
     }
     // compact the used slots into the pose's place, slot order (as k_assoc_group does)
     const int room = (plan1 - plan0) + kStageSlack;
@@ -1335,8 +1366,10 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
             const unsigned q = (unsigned)(written + prefix_count(mask, lane));
             *reinterpret_cast<int*>(reinterpret_cast<char*>(st_label + sbase) + (q << 2)) = key;
             *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(st_k + sbase) + (q << 1)) = (unsigned short)T.cnt[s];
+#ifndef ICM_EXP_NOSTORE
             *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sbx + sbase) + (q << 3)) = T.sx[s];
             *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sby + sbase) + (q << 3)) = T.sy[s];
+#endif
             isnew |= key == -1;
             if (DEBUG) T.owner[s] = q;
         }
@@ -1351,6 +1384,10 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
         if (overflow) flags[0] = 1;
         if (run_counts && n_und) atomicAdd(&run_counts[1], (unsigned long long)n_und);   // (runs that went beam by beam: rare, counted over the handle's life)
     }
+#ifdef ICM_ASSOC_TS
+    ASSOC_TS(6);
+    ASSOC_TS_VAL(7, nbatch);
+#endif
     if (DEBUG) {  // beam -> entry index within the pose
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();

@@ -127,6 +127,25 @@ def sweep(cfg, kept, u, odo, x0, mapa_viejo, x, lact=None, schedule="sequential"
     return mo[:, :Ko.value].copy(), co, int(Ko.value), (yr, cr, int(la.value))
 
 
+def init_pass(cfg, kept, u, odo, y0, cnt0, lact0):
+    """The causal initialisation pass (scripts/ICM_ROS.py:102-119) from the map the first scan's clustering seeds
+    (y0 (2,L), cnt0 (L), lact0: oracle/icm_oracle.py cluster_first_scan).  Returns (x (3,T), raw y (2,L), counts (L), lact)."""
+    lib = load()
+    c = _cfg(cfg)
+    off, k, d, ang, bx, by = kept
+    T = odo.shape[1]
+    y, cnt = _f(y0).copy(), _f(cnt0).copy()
+    la = C.c_int64(int(lact0))
+    x = np.zeros((3, T))
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    d, ang, bx, by, odo, u = _f(d), _f(ang), _f(bx), _f(by), _f(odo), _f(u)
+    rc = lib.oc_init_pass(C.byref(c), C.c_int64(T), off.ctypes.data_as(_lp), _p(d), _p(ang), _p(bx), _p(by), _p(odo), _p(u),
+                          _p(y), _p(cnt), C.byref(la), _p(x))
+    if rc == -3:
+        raise IndexError("oracle: label capacity exceeded in the initialisation pass")
+    return x, y, cnt, int(la.value)
+
+
 def solve_one(cfg, two_sided, x_ant, x_pos, u, odo, beams_d_ang, targets):
     lib = load()
     c = _cfg(cfg)

@@ -458,6 +458,74 @@ int oc_sweep2(const oc_config* cfg, int64_t T, const int64_t* off, const double*
     return rc;
 }
 
+/* ---- the causal initialisation pass, scripts/ICM_ROS.py:102-119 (inicializar_online_process) on recorded data ----
+ * The map y (2,L) / cnt (L) / *lact arrive seeded by the first scan's clusters (Mapa.actualizar's Lact == 0 branch,
+ * scripts/ICM_SLAM_tools.py:160-165: SciPy's linkage, done by the caller); then for t = 1 .. T-1: predict with g,
+ * project the kept beams with the prediction, associate against the RUNNING map (:168-172), fold the scan into it
+ * (:184-195), one-sided solve from g(x_{t-1}, u_{t-1}) (minimizar_x, scripts/ICM_ROS.py:253-262).  x (3,T) out; x[:,0]
+ * = odo[:,0].  Returns 0 or -3 (label capacity). */
+int oc_init_pass(const oc_config* cfg, int64_t T, const int64_t* off, const double* bd, const double* bang,
+                 const double* bx, const double* by, const double* odo, const double* u, double* y, double* cnt,
+                 int64_t* lact_io, double* x) {
+    const int64_t L = cfg->L;
+    int64_t lact = *lact_io, maxn = 0;
+    for (int64_t t = 0; t < T; ++t) if (off[t + 1] - off[t] > maxn) maxn = off[t + 1] - off[t];
+    double* wx = (double*)malloc(sizeof(double) * (size_t)(4 * maxn + 4));
+    double *wy = wx + maxn + 1, *tx = wy + maxn + 1, *ty = tx + maxn + 1;
+    int64_t* lab = (int64_t*)malloc(sizeof(int64_t) * (size_t)(maxn + 1));
+    double xt[3] = {odo[0], odo[T], odo[2 * T]};
+    x[0] = xt[0]; x[T] = xt[1]; x[2 * T] = xt[2];
+    int rc = 0;
+    for (int64_t t = 1; t < T && rc == 0; ++t) {
+        const double ua[2] = {u[t - 1], u[T + t - 1]};
+        double xc[3];
+        g_step(cfg, xt, ua, xc);
+        const int64_t j0 = off[t], n = off[t + 1] - j0;
+        if (n > 0) {
+            const double ct = cos(xc[2] - HALF_PI), st = sin(xc[2] - HALF_PI);
+            int anynew = 0;
+            for (int64_t j = 0; j < n; ++j) {
+                wx[j] = (bx[j0 + j] * ct + by[j0 + j] * (-st)) + xc[0];
+                wy[j] = (bx[j0 + j] * st + by[j0 + j] * ct) + xc[1];
+                lab[j] = associate_point(0, y, y + L, lact, wx[j], wy[j], cfg->dist_thr);
+                if (lab[j] < 0) anynew = 1;
+            }
+            if (anynew) {
+                if (lact >= L) { rc = -3; break; }
+                for (int64_t j = 0; j < n; ++j) if (lab[j] < 0) lab[j] = lact;
+                ++lact;
+            }
+            for (int64_t j = 0; j < n; ++j) {
+                int leader = 1;
+                for (int64_t q = 0; q < j; ++q) if (lab[q] == lab[j]) { leader = 0; break; }
+                if (!leader) continue;
+                double sx = 0.0, sy = 0.0; int64_t k = 0;
+                for (int64_t q = j; q < n; ++q) if (lab[q] == lab[j]) { sx += wx[q]; sy += wy[q]; ++k; }
+                const int64_t i = lab[j];
+                const double nn = cnt[i], tot = nn + (double)k;
+                y[i] = sx / tot + y[i] * nn / tot;
+                y[L + i] = sy / tot + y[L + i] * nn / tot;
+                cnt[i] = tot;
+            }
+            for (int64_t j = 0; j < n; ++j) { tx[j] = y[lab[j]]; ty[j] = y[L + lab[j]]; }
+            pose_problem p;
+            p.cfg = cfg; p.two_sided = 0; p.n = n;
+            p.d = bd + j0; p.ang = bang + j0; p.tx = tx; p.ty = ty;
+            for (int r = 0; r < 3; ++r) { p.xa[r] = xt[r]; p.oa[r] = odo[r * T + t - 1]; p.ot[r] = odo[r * T + t]; p.xp[r] = 0.0; p.op[r] = 0.0; }
+            p.ua[0] = ua[0]; p.ua[1] = ua[1]; p.ut[0] = p.ut[1] = 0.0;
+            double st0[3];
+            g_step(cfg, p.xa, p.ua, st0);
+            nelder_mead(&p, st0, xt, 0, 0);
+        } else {
+            xt[0] = xc[0]; xt[1] = xc[1]; xt[2] = xc[2];
+        }
+        x[t] = xt[0]; x[T + t] = xt[1]; x[2 * T + t] = xt[2];
+    }
+    *lact_io = lact;
+    free(lab); free(wx);
+    return rc;
+}
+
 int oc_sweep(const oc_config* cfg, int64_t T, const int64_t* off, const double* bd, const double* bang,
              const double* bx, const double* by, const double* odo, const double* u, const double* x0,
              const double* map_in, int64_t K, int64_t lact_in, int schedule, double* x, double* map_out,

@@ -164,6 +164,26 @@ def test_c_oracle_matches_reference_goldens():
         assert np.abs(x - g["x"]).max() <= 1e-9 and np.abs(mv - g["mapa"]).max() <= 1e-9
 
 
+def test_c_oracle_init_pass_matches_the_reference(cfg, kept):
+    """The C restatement of the causal initialisation pass (scripts/ICM_ROS.py:102-119) from the map the first scan's
+    clustering seeds, against the reference's own x_init / raw map / counters (init_pass.npz)."""
+    from oracle import c_oracle as co
+    from util import Cfg
+    zz, odo, u = dataset()
+    g = gold("init_pass.npz")
+    cc = Cfg()
+    st = o.MapState(cfg)
+    y0 = np.zeros((2, cfg.L))
+    y0, c0 = o.cluster_first_scan(st, y0, o.project_beams(odo[:, 0].copy(), kept[0][:, 2:4]))
+    assert np.array_equal(c0, g["labels_scan0"])
+    x, y, cnt, lact = co.init_pass(cc, co.prefilter(cc, zz), u, odo, y0, st.cant_obs_i, st.landmarks_actuales)
+    assert lact == int(g["landmarks_raw"]) and np.array_equal(cnt, g["cant_obs_raw"])
+    assert np.abs(y - g["y_raw"]).max() <= 1e-12
+    d = np.abs(x - g["x_init"]).max()
+    print("C init pass vs the reference: max|dx| %.2e" % d)
+    assert d <= 1e-9
+
+
 def test_c_oracle_equals_numpy_oracle_redblack(cfg, kept):
     from oracle import c_oracle as co
     from util import Cfg
