@@ -110,16 +110,26 @@ def test_brute_force_equals_grid_at_s1_size():
     eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
     eng.set_debug(True)
     out = []
-    for brute in (False, True):
+    for brute, form in ((False, "beams"), (True, "beams"), (False, "runs")):
         eng.set_brute_force(brute)
+        eng.set_assoc_form(form)
         eng.set_state(wl.map_init, wl.x_init, wl.x0)
         eng.sweep_device("redblack")
         out.append((eng.association()[0].copy(),) + eng.get_state())
     eng.close()
+    # beam by beam, grid search against the all-landmarks search: the same labels, and then the same arithmetic
     assert np.array_equal(out[0][0], out[1][0])
     for a, b in zip(out[0][1:], out[1][1:]):
         assert np.array_equal(a, b)
     assert (out[0][0] >= 0).all()
+    # by runs (the default form): the same labels and counters; the per-entry sums are added up run by run, so real-valued
+    # state agrees to rounding (<= 1e-9 like everywhere; bit-identical poses are reported, not required)
+    assert np.array_equal(out[2][0], out[1][0])
+    x2, m2, c2, K2 = out[2][1:]
+    x1, m1, c1, K1 = out[1][1:]
+    assert K2 == K1 and np.array_equal(c2, c1)
+    print("run form vs brute force: max|dmap| %.2e  max|dx| %.2e  poses bit-identical: %s" % (np.abs(m2 - m1).max(), np.abs(x2 - x1).max(), np.array_equal(x2, x1)))
+    assert np.abs(m2 - m1).max() <= 1e-9 and np.abs(x2 - x1).max() <= 1e-9
 
 
 def test_prefilter_edge_cases_match_the_oracle():
@@ -196,17 +206,27 @@ def test_crowded_neighbourhoods_take_the_rest_of_the_record_and_the_walk():
     eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
     eng.set_debug(True)
     out = []
-    for brute in (False, True):
+    for brute, form in ((False, "beams"), (True, "beams"), (False, "runs")):
         eng.set_brute_force(brute)
+        eng.set_assoc_form(form)
         eng.set_state(m, wl.x_init, wl.x0)
         eng.sweep_device("redblack")
         out.append((eng.association()[0].copy(),) + eng.get_state())
+    n_runs, beam_by_beam = eng.run_counts()
     eng.close()
     assert np.array_equal(out[0][0], out[1][0])
     for a, b in zip(out[0][1:], out[1][1:]):
         assert np.array_equal(a, b)
     # the decoys are really in play: a share of the beams goes to them (10 % here)
     assert (out[0][0] >= m0.shape[1]).mean() > 0.05
+    # the run form on the same crowded map (few runs are settled by their bounding circle here): same labels, same
+    # counters, state to rounding
+    assert np.array_equal(out[2][0], out[1][0])
+    assert out[2][4] == out[1][4] and np.array_equal(out[2][3], out[1][3])
+    print("crowded map, run form: %d of %d runs beam by beam; vs brute force max|dmap| %.2e max|dx| %.2e"
+          % (beam_by_beam, n_runs, np.abs(out[2][2] - out[1][2]).max(), np.abs(out[2][1] - out[1][1]).max()))
+    assert beam_by_beam > n_runs // 2
+    assert np.abs(out[2][2] - out[1][2]).max() <= 1e-9 and np.abs(out[2][1] - out[1][1]).max() <= 1e-9
 
 
 def test_s2_full_size_properties():
