@@ -1560,7 +1560,11 @@ int icm_sweep_solve(icm_handle* h, int schedule, int colour) {
         else if (h->form == 2) TIMED(h, KID_SOLVE, (k_solve_sequential<false><<<1, kWave, 0, h->stream>>>(a)));
         else {
             const bool iso = h->cfg.Q[0] == h->cfg.Q[1] && h->cfg.R[0] == h->cfg.R[1];
-            if (h->fold_mode < 0 ? iso : h->fold_mode == 1) TIMED(h, KID_SOLVE, (k_solve_m_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
+            const bool fold = h->fold_mode < 0 ? iso : h->fold_mode == 1;
+            if (h->solve_quad == 1) {   // (icm_set_solve_lanes(1): the quad form of the chain, a cross-check)
+                if (fold) TIMED(h, KID_SOLVE, (k_solve_m_sequential<true, true><<<1, kWave, 0, h->stream>>>(a)));
+                else TIMED(h, KID_SOLVE, (k_solve_m_sequential<false, true><<<1, kWave, 0, h->stream>>>(a)));
+            } else if (fold) TIMED(h, KID_SOLVE, (k_solve_m_sequential<true><<<1, kWave, 0, h->stream>>>(a)));
             else TIMED(h, KID_SOLVE, (k_solve_m_sequential<false><<<1, kWave, 0, h->stream>>>(a)));
             h->rot_valid = false;   // (the chain does not keep the rotation pairs: k_pose_rot at the head of the next sweep)
         }

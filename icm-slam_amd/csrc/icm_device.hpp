@@ -763,22 +763,28 @@ __device__ __forceinline__ bool nelder_mead3(F f, double sx, double sy, double s
 template <int K>
 __device__ __forceinline__ double quad_bcast(double v) {  // value of lane K of the quad, in all four lanes
     constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);  // quad_perm:[K,K,K,K]
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, false);
+    int sl = __double2loint(v), sh = __double2hiint(v);
+    asm("" : "+v"(sl), "+v"(sh));   // (a DPP source is a vector register, also where the value happens to be wave-uniform: k_init_pass)
+    const int lo = __builtin_amdgcn_update_dpp(0, sl, ctrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, sh, ctrl, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 
 // true in all four lanes of a DPP quad when it holds in one of them
 __device__ __forceinline__ bool quad_any(bool b) {
     int v = b ? 1 : 0;
+    asm("" : "+v"(v));
     v |= __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
     v |= __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
     return v != 0;
 }
 
-template <class F>
-__device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, double st, int role, double out[6]) {
-    const int maxfun = 600, maxiter = 600;
+template <class F, class S = NeverStop>
+__device__ __forceinline__ bool nelder_mead3_quad(F f, double sx, double sy, double st, int role, double out[6], S stop = S()) {
+    // Written like nelder_mead3: one straight-line iteration with predicates, ONE evaluation call site in the loop (lane
+    // `role` of the quad evaluates point `role`: reflection, expansion, outside, inside contraction), the shrink a rarely
+    // entered block, one loop condition at the bottom.  `stop` must be quad-uniform (the caller folds it over the quad).
+    constexpr int maxfun = 600, maxiter = 600;
     const double xatol = 1e-3, fatol = 1e-4;
     const double grow = 1 + 0.05;
     Vtx v0{sx, sy, st, 0.0};
@@ -798,49 +804,46 @@ __device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, dou
     }
     int nfev = 4, it = 1;
     sort4(v0, v1, v2, v3);
-    // point r of an iteration = ca[r] * xbar + cb[r] * sim[-1]
+    // point `role` of an iteration = ca xbar + cb sim[-1]: (2, -1), (3, -2), (1.5, -0.5), (0.5, 0.5); cb sim[-1] is exact,
+    // so fma(cb, x_w, ca xbar) rounds like the scalar form's reflection 2 xbar - x_w and its second point
     const double ca = role == 0 ? 2.0 : (role == 1 ? 3.0 : (role == 2 ? 1.5 : 0.5));
     const double cb = role == 0 ? -1.0 : (role == 1 ? -2.0 : (role == 2 ? -0.5 : 0.5));
-    while (nfev < maxfun && it < maxiter) {
+    auto settled = [&]() {
         const double dx = fmax(fmax(amax3(v1, v0), amax3(v2, v0)), amax3(v3, v0));
         const double df = fmax(fmax(fabs(v0.f - v1.f), fabs(v0.f - v2.f)), fabs(v0.f - v3.f));
-        if (dx <= xatol && df <= fatol) break;
+        return (dx <= xatol) & (df <= fatol);
+    };
+    bool stopped = stop();
+    bool go = !(settled() | stopped);
+    while (go) {
         const double bx = div3((v0.x + v1.x) + v2.x);
         const double by = div3((v0.y + v1.y) + v2.y);
         const double bt = div3((v0.t + v1.t) + v2.t);
-        // my point (role 0: 2*xbar - sim[-1], written so that it rounds like the scalar form)
-        const double mx = role == 0 ? 2 * bx - v3.x : ca * bx + cb * v3.x;
-        const double my = role == 0 ? 2 * by - v3.y : ca * by + cb * v3.y;
-        const double mt = role == 0 ? 2 * bt - v3.t : ca * bt + cb * v3.t;
+        const double mx = fma_(cb, v3.x, ca * bx), my = fma_(cb, v3.y, ca * by), mt = fma_(cb, v3.t, ca * bt);
         const double fm = f(mx, my, mt);
         Vtx r{quad_bcast<0>(mx), quad_bcast<0>(my), quad_bcast<0>(mt), quad_bcast<0>(fm)};
         ++nfev;
-        int kind = 0;
-        if (r.f < v0.f) kind = 1;
-        else if (r.f < v2.f) kind = 0;
-        else if (r.f < v3.f) kind = 2;
-        else kind = 3;
-        bool shrink = false, aborted = false;
-        if (kind != 0) {
-            if (nfev >= maxfun) {
-                aborted = true;
-            } else {
-                Vtx t;
-                if (kind == 1) t = Vtx{quad_bcast<1>(mx), quad_bcast<1>(my), quad_bcast<1>(mt), quad_bcast<1>(fm)};
-                else if (kind == 2) t = Vtx{quad_bcast<2>(mx), quad_bcast<2>(my), quad_bcast<2>(mt), quad_bcast<2>(fm)};
-                else t = Vtx{quad_bcast<3>(mx), quad_bcast<3>(my), quad_bcast<3>(mt), quad_bcast<3>(fm)};
-                ++nfev;
-                if (kind == 1) v3 = (t.f < r.f) ? t : r;
-                else if (kind == 2) { if (t.f <= r.f) v3 = t; else shrink = true; }
-                else { if (t.f < v3.f) v3 = t; else shrink = true; }
-            }
-        } else {
-            v3 = r;
-        }
-        if (shrink) {
-            // sim[j] = sim[0] + sigma (sim[j] - sim[0]), j = 1..3, each followed by its evaluation;
-            // a call beyond maxfun aborts after the vertex was moved (SciPy's order)
-            const int room = maxfun - nfev;  // evaluations still allowed (>= 1 here is not guaranteed)
+        const bool lt0 = r.f < v0.f, lt2 = r.f < v2.f, lt3 = r.f < v3.f;
+        const bool need2 = lt0 | !lt2;
+        const bool can2 = need2 & (nfev < maxfun);
+        // the second point: expansion (lane 1), outside (lane 2) or inside (lane 3) contraction
+        const double e1x = quad_bcast<1>(mx), e1y = quad_bcast<1>(my), e1t = quad_bcast<1>(mt), e1f = quad_bcast<1>(fm);
+        const double e2x = quad_bcast<2>(mx), e2y = quad_bcast<2>(my), e2t = quad_bcast<2>(mt), e2f = quad_bcast<2>(fm);
+        const double e3x = quad_bcast<3>(mx), e3y = quad_bcast<3>(my), e3t = quad_bcast<3>(mt), e3f = quad_bcast<3>(fm);
+        Vtx t{lt0 ? e1x : (lt3 ? e2x : e3x), lt0 ? e1y : (lt3 ? e2y : e3y), lt0 ? e1t : (lt3 ? e2t : e3t), lt0 ? e1f : (lt3 ? e2f : e3f)};
+        nfev += can2 ? 1 : 0;
+        const bool t_lt_r = t.f < r.f, t_le_r = t.f <= r.f, t_lt_w = t.f < v3.f;
+        const bool take_t = (lt0 & t_lt_r) | (!lt0 & lt3 & t_le_r) | (!lt3 & t_lt_w);
+        const bool shrink = can2 & !lt0 & !take_t;
+        const bool aborted0 = need2 & !can2;
+        const bool use_t = can2 & take_t;
+        const bool keep = shrink | aborted0;
+        insert_vertex(v0, v1, v2, v3, r, t, use_t, !keep);
+        bool aborted = aborted0;
+        if (__builtin_expect(shrink, 0)) {
+            // sim[j] = sim[0] + sigma (sim[j] - sim[0]), j = 1..3, each followed by its evaluation; a call beyond maxfun
+            // aborts after the vertex was moved (SciPy's order)
+            const int room = maxfun - nfev;
             Vtx n1 = v1, n2 = v2, n3 = v3;
             n1.x = v0.x + 0.5 * (v1.x - v0.x); n1.y = v0.y + 0.5 * (v1.y - v0.y); n1.t = v0.t + 0.5 * (v1.t - v0.t);
             n2.x = v0.x + 0.5 * (v2.x - v0.x); n2.y = v0.y + 0.5 * (v2.y - v0.y); n2.t = v0.t + 0.5 * (v2.t - v0.t);
@@ -863,16 +866,15 @@ __device__ __forceinline__ void nelder_mead3_quad(F f, double sx, double sy, dou
                 nfev += room > 0 ? room : 0;
             }
             sort4(v0, v1, v2, v3);
-        } else {
-            cswap(v2, v3);
-            cswap(v1, v2);
-            cswap(v0, v1);
         }
-        if (aborted) break;
-        ++it;
+        it += aborted ? 0 : 1;
+        stopped = stop();
+        static_assert(maxfun <= maxiter + 3, "the evaluation budget implies the iteration budget");
+        go = !aborted & (nfev < maxfun) & !(settled() | stopped);
     }
     out[0] = v0.x; out[1] = v0.y; out[2] = v0.t; out[3] = v0.f;
     out[4] = (double)it; out[5] = (double)nfev;
+    return stopped;
 }
 
 }  // namespace icm

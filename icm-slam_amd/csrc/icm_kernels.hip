@@ -3019,7 +3019,6 @@ __device__ __forceinline__ bool solve_pose_in(const SolveArgs& a, int tg, const 
     }
     double out[6];
     if (FOLD) {
-        static_assert(!(FOLD && QUAD), "the fold-only solve is the lane form");
         bool left = false;    // an evaluation since the Nelder-Mead last asked left the folded form's range
         const PinnedTrigK trig;
         auto ef = [&](double px, double py, double th) {
@@ -3028,8 +3027,13 @@ __device__ __forceinline__ bool solve_pose_in(const SolveArgs& a, int tg, const 
             left |= !ok;
             return e;
         };
-        auto stop = [&]() { const bool l = left; left = false; return l; };
-        if (nelder_mead3(ef, sx, sy, st, out, stop)) return false;
+        if (QUAD) {   // (any of the quad's four points: a point the iteration discards may ask for the second solve too -- same result)
+            auto stopq = [&]() { const bool l = quad_any(left); left = false; return l; };
+            if (nelder_mead3_quad(ef, sx, sy, st, role, out, stopq)) return false;
+        } else {
+            auto stop = [&]() { const bool l = left; left = false; return l; };
+            if (nelder_mead3(ef, sx, sy, st, out, stop)) return false;
+        }
     } else if (QUAD) {
         nelder_mead3_quad([&](double px, double py, double th) { return pose_energy_moments(c, m, f, px, py, th); }, sx, sy, st, role, out);
     } else {
@@ -3303,10 +3307,29 @@ __global__ __launch_bounds__(kBlock) void k_solve_mq_colour(SolveArgs a, SolveSe
 // the rotation pairs kept beside the poses are NOT written here -- two generic sincos per pose on a chain of T - 1
 // solves -- but by k_pose_rot at the head of the next sweep, in parallel (the host clears rot_valid).  data_IJAC2018:
 // 53 -> ?? ms per sweep; the same arithmetic per pose as every other solve form (bit-identical).
-template <bool FOLD>
+// Round 5 measured the chain walked by ONE DPP QUAD (QUAD = true: nelder_mead3_quad, the four candidate points of an
+// iteration evaluated at once, lane r point r, the folded energy in the loop -- one evaluation of latency per iteration
+// instead of two): 45.2 against 43.1 ms on data_IJAC2018, and 55.3 against 50.6 ms for k_init_pass.  The folded energy
+// is ~40 of an iteration's ~210 instructions; what the chain costs is the Nelder-Mead's bookkeeping, which the quad does
+// not shorten (it adds the exchanges), at one dependent instruction per ~4.6 cycles of a lone wave.  Kept as a
+// cross-check (bit-identical), the lane form is what runs.
+template <bool FOLD, bool QUAD = false>
 __global__ __launch_bounds__(kWave) void k_solve_m_sequential(SolveArgs a) {
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x >= (QUAD ? 4 : 1)) return;
+    const int role = threadIdx.x;
     double prev[3] = {a.x[0], a.x[1], a.x[2]};
+    if constexpr (!FOLD) {
+        // the complete energy in the loop (anisotropic weights; a cross-check otherwise): load and solve, no prefetch -- with
+        // the next pose's inputs carried around this larger loop the compiler keeps them in scratch behind a flat pointer
+        // and its null check does not assemble on gfx950
+        for (int tg = 1; tg < a.T; ++tg) {
+            double res[3];
+            solve_pose_moments<QUAD, false>(a, tg, prev, false, res, role);
+            if (role == 0) store_pose_xyz(a, tg, res, false);
+            prev[0] = res[0]; prev[1] = res[1]; prev[2] = res[2];
+        }
+        return;
+    }
     PoseIn cur;
     cur.n = 0;
     if (a.T > 1) load_pose_in(a, 1, cur);
@@ -3315,16 +3338,16 @@ __global__ __launch_bounds__(kWave) void k_solve_m_sequential(SolveArgs a) {
         nxt.n = 0;
         if (tg + 1 < a.T) load_pose_in(a, tg + 1, nxt);
         double r0 = 0.0, r1 = 0.0, r2 = 0.0;
-        bool ok = solve_pose_in<false, FOLD>(a, tg, cur, prev, false, r0, r1, r2);   // (prev is the pose this lane has just solved: its pair is formed here)
+        bool ok = solve_pose_in<QUAD, FOLD>(a, tg, cur, prev, false, r0, r1, r2, role);   // (prev is the pose this lane / quad has just solved: its pair is formed here)
         if (FOLD && !ok) {
             int tgc = tg;
             asm volatile("" : "+v"(tgc));
             double res[3];
-            solve_pose_moments<false, false>(a, tgc, prev, false, res);
+            solve_pose_moments<QUAD, false>(a, tgc, prev, false, res, role);
             r0 = res[0]; r1 = res[1]; r2 = res[2];
         }
         const double res[3] = {r0, r1, r2};
-        store_pose_xyz(a, tg, res, false);
+        if (role == 0) store_pose_xyz(a, tg, res, false);
         prev[0] = r0; prev[1] = r1; prev[2] = r2;
         cur = nxt;
     }
@@ -3507,6 +3530,7 @@ __global__ __launch_bounds__(kWave) void k_init_pass(InitArgs a) {
             double r0 = 0.0, r1 = 0.0, r2 = 0.0;
             const bool iso = a.Q0 == a.Q1 && a.R0 == a.R1;
             bool ok = false;
+            // (the quad form here -- every DPP quad of the wave on the same numbers -- measured 55.3 against 50.6 ms: k_solve_m_sequential)
             if (iso) ok = solve_pose_in<false, true>(sa, t, in, xt, false, r0, r1, r2);
             if (!ok) solve_pose_in<false, false>(sa, t, in, xt, false, r0, r1, r2);
             xt[0] = r0; xt[1] = r1; xt[2] = r2;

@@ -507,6 +507,24 @@ def test_quad_latency_solver_is_bit_identical():
         assert np.array_equal(a, b)
     assert np.array_equal(res[0][1], res[1][1])          # f, nit, nfev of every pose
     assert res[0][1][:, 2].max() > 60
+    # the reference's own order (one dependent chain, scripts/ICM_ROS.py:141-158) walked by one lane / one DPP quad, with the
+    # folded energy in the loop (automatic) and with the complete energy there (fold mode 0): poses, f, nit, nfev identical
+    eng = SweepEngine(Cfg())
+    eng.upload(zz, odo, u)
+    eng.set_debug(True)
+    seq = {}
+    for fold in (-1, 0):
+        for mode in (0, 1):
+            eng.set_fold_mode(fold)
+            eng.set_solve_lanes(mode)
+            eng.set_state(init["map_init"], init["x_init"], odo[:, 0], 11)
+            eng.sweep_device("sequential")
+            seq[(fold, mode)] = (eng.get_state(), eng.solve_diag().copy())
+    eng.close()
+    for key in ((-1, 1), (0, 0), (0, 1)):
+        for a, b in zip(seq[(-1, 0)][0], seq[key][0]):
+            assert np.array_equal(a, b), key
+        assert np.array_equal(seq[(-1, 0)][1][:, 1:], seq[key][1][:, 1:]), key     # nit, nfev of every pose
     wl = make_workload(1900, 100, 180)
     e2 = SweepEngine(ConfigICM(D=wl.config))
     e2.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
