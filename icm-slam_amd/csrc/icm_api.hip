@@ -213,7 +213,7 @@ struct icm_handle {
     double ph_ms[5] = {0, 0, 0, 0, 0};   // local | exchange (+ waiting for the slowest rank) | targets | solve | host time in finish
     int64_t ph_n = 0;
     int solve_ppw = 0;   // poses per wave of the one-launch solve: 0 automatic, 32 or 64 (ICM_SOLVE_PPW)
-    int fault = 0;   // test hook (icm_set_fault): 1 = the next icm_sweep_local reports a HIP error
+    int fault = 0;   // test hook (icm_set_fault): 1 = the next icm_sweep_local reports a HIP error, 2 = the next icm_sweep_targets does (behind the exchange)
     int64_t dropin_counts[3] = {0, 0, 0};   // icm_sweep calls: [0] started without an upload, [1] of those: the check failed (started over), [2] poses mirrored into the caller's array
     double h_x0[3] = {0, 0, 0};      // host copy of x0 as uploaded
     bool x_mirrored = false;         // the sweep's solve launch wrote the poses into x_mirror
@@ -248,7 +248,8 @@ struct icm_handle {
     bool defer_filtrar = false;     // set by the library's own sweep drivers: Mapa.filtrar's launches are queued behind the solve launch (icm_sweep_targets)
     bool filtrar_deferred = false;  // ... and this sweep's are still to be queued
     bool map_by_spinner = false;    // ... or there is no event: the side stream polls the word k_lm_l3's last workgroup sets
-    bool l3_spin = true;            // (ICM_L3_EVENT=1: the stop event, for A/B runs)
+    bool l3_spin = true;            // (ICM_L3_EVENT=1: the stop event, for A/B runs; cleared for good by a wait that gave up)
+    int64_t wait_giveups = 0;       // sweeps whose k_wait_word gave up (icm_get_wait_giveups)
     DevBuf<int> l3_done;            // [0] workgroups of k_lm_l3 through, [1] epoch of the launch that finished last, [2] epoch of a wait that gave up
     int l3_epoch = 0;
     bool map_copy_pending = false;
@@ -285,6 +286,7 @@ struct icm_handle {
         }                                                                      \
     } while (0)
 
+constexpr int kWaitPolls = 1 << 14;   // k_wait_word: ~1 us a poll, i.e. ~16 ms -- phase A + levels 1-3 of the longest sequence this build takes are a few ms
 constexpr int kStalePoses = 1001;   // internal (icm_sweep_finish -> icm_sweep): the sweep ran from device poses that were not the caller's; nothing was replaced
 constexpr int kStaleWord = 20;      // of the host's mapped block: the epoch of the call whose pose check failed
 static inline double host_now_ms() {
@@ -1180,7 +1182,7 @@ int icm_sweep_local(icm_handle* h) {
                     // in icm_sweep_targets, starts a kernel boundary after the raw map is out, and nothing stands on the
                     // main queue between k_lm_l3 and k_rec_push (the stop event cost 5-6 us there).
                     ++h->l3_epoch;
-                    k_wait_word<<<1, kWave, 0, h->copy_stream>>>(h->l3_done.p + 1, h->l3_epoch, 1 << 16, h->l3_done.p + 2);
+                    k_wait_word<<<1, kWave, 0, h->copy_stream>>>(h->l3_done.p + 1, h->l3_epoch, kWaitPolls, h->l3_done.p + 2);
                 }
                 hipExtLaunchKernelGGL(k_lm_l3, dim3((L + kWave - 1) / kWave), dim3(kBlock), 0, h->stream, nullptr, (map_final && !spin) ? h->ev_map : nullptr, 0,
                     h->nsuper, L, h->lact0, (const int*)(run_scan ? h->new_rank.p + nloc : h->fl + 9), ms, ms + msn, ms + 2 * msn, stats_mine, h->y_raw.p, h->cnt_raw.p,
@@ -1296,10 +1298,10 @@ static int launch_ghost(icm_handle* h) {
 // do not wait for it; after the exchange every rank looks at every header (icm_failed_rank) and fails together.
 int icm_mark_failed(icm_handle* h, int code) {
     if (!h) return ICM_ERR_ARG;
-    if (code >= 0) FAIL(h, ICM_ERR_ARG, "icm_mark_failed: an error code is negative");
+    if (code > 0) FAIL(h, ICM_ERR_ARG, "icm_mark_failed: an error code is negative (0: a clean header, the closing exchange)");
     if (!h->have_state || (h->world > 1 && !h->stats_all)) FAIL(h, ICM_ERR_ARG, "icm_mark_failed: no state / no exchange buffer");
     HIPCHK(h, hipSetDevice(h->device));
-    k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), (int)h->cfg.L, 0.0, (double)(1 - code), h->x, edge_first(h), edge_last(h), edge_last2(h));
+    k_set_header<<<1, 1, 0, h->stream>>>(stats_slot(h), (int)h->cfg.L, 0.0, code ? (double)(1 - code) : 0.0, h->x, edge_first(h), edge_last(h), edge_last2(h));
     HIPCHK(h, hipGetLastError());
     return ICM_OK;
 }
@@ -1337,6 +1339,10 @@ static int queue_filtrar(icm_handle* h, bool ev_map_recorded);
 // After the (optional) all-gather: offsets, raw map, targets.
 int icm_sweep_targets(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
+    if (h->fault == 2) {
+        h->fault = 0;
+        FAIL(h, ICM_ERR_HIP, "icm_sweep_targets: injected fault (icm_set_fault)");
+    }
     if (!h->have_state) FAIL(h, ICM_ERR_ARG, "icm_sweep_targets: no state");
     if (h->scan0_empty) return ICM_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1667,6 +1673,12 @@ int icm_sweep_finish(icm_handle* h) {
     if (h->lact_raw > (int64_t)L) FAIL(h, ICM_ERR_INDEX, "sweep: new landmarks exceed the map capacity L");
     h->raw_on_device = true;   // (raw map and counters stay in y_raw / cnt_raw until somebody asks: fetch_raw_map)
     h->filtrar_path = 2;
+    if (h->map_by_spinner && h->gpu_filtrar && h->pin_i[9] == 3) {
+        // the side stream's wait for the raw map gave up (k_wait_word): the streams are serialised somewhere.  This sweep's
+        // Mapa.filtrar runs on the host below; later sweeps start the side stream by k_lm_l3's stop event, which cannot starve.
+        ++h->wait_giveups;
+        h->l3_spin = false;
+    }
     if (h->gpu_filtrar && h->pin_i[9] == 1) {
         // survivors closer than dist_thr: merged on the device (rare; one extra round trip)
         int rc = launch_filtrar_merge(h, h->copy_stream, h->pin_i[8]);
@@ -1973,7 +1985,7 @@ int icm_sweep_sharded(icm_handle* h) {
             if ((rc2 = icm_exchange_status(h, &fr, &code, nullptr))) { rc = rc2; break; }
             if (fr >= 0) {
                 h->opt_req = req;
-                FAIL(h, code, "sharded sweep: rank " + std::to_string(fr) + " failed in phase A (" + phase_a_error_text(code) + ")");
+                FAIL(h, code, "sharded sweep: rank " + std::to_string(fr) + " failed (" + phase_a_error_text(code) + ")");
             }
         }
     }
@@ -2016,12 +2028,41 @@ static int sweep_sharded_once(icm_handle* h) {
         int fr = -1, code = 0, retry = 0;
         if ((rc = icm_exchange_status(h, &fr, &code, &retry))) return rc;
         if (fr >= 0)
-            FAIL(h, code, "sharded sweep: rank " + std::to_string(fr) + " failed in phase A (" + phase_a_error_text(code) + ")");
+            FAIL(h, code, "sharded sweep: rank " + std::to_string(fr) + " failed (" + phase_a_error_text(code) + ")");
         if (retry) return ICM_RETRY_CAREFUL;
     }
-    if ((rc = icm_sweep_targets(h))) return rc;
-    if ((rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, -1))) return rc;
-    return icm_sweep_finish(h);
+    // Behind the exchange a rank can still fail on its own (a device error in the targets, the solve launch or
+    // Mapa.filtrar; its peers, whose phases ran, are on their way to the NEXT exchange -- the next sweep's, or the closing
+    // one of icm_gather_poses / icm_sharded_end).  It meets them there: one more message with the code in its header and
+    // nothing else (farewell), so that every rank returns the error one exchange later instead of waiting for a rank that
+    // has left; a rank that cannot even do that aborts the communicator.
+    rc = icm_sweep_targets(h);
+    if (!rc) rc = icm_sweep_solve(h, ICM_SCHEDULE_REDBLACK, -1);
+    if (!rc) rc = icm_sweep_finish(h);
+    if (rc < 0) {
+        const std::string err_local = h->err;
+        int rf = icm_mark_failed(h, rc);
+        if (!rf) rf = all_gather(h, h->own_stats_send.p, h->own_stats_all.p, stride);
+        if (rf) comm_abort(h);
+        h->err = err_local;
+    }
+    return rc;
+}
+
+// The closing exchange of a sharded job: one more all-gather of the statistics message with a clean header, after the
+// last sweep -- where a rank that failed BEHIND the last sweep's exchange delivers its error (sweep_sharded_once).
+// icm_gather_poses runs it first.
+int icm_sharded_end(icm_handle* h) {
+    if (!h) return ICM_ERR_ARG;
+    if (!h->comm_ready) FAIL(h, ICM_ERR_ARG, "icm_sharded_end: no communicator (icm_comm_init)");
+    if (h->world <= 1 || !h->have_state) return ICM_OK;
+    int rc = icm_mark_failed(h, 0);
+    if (!rc) rc = all_gather(h, h->own_stats_send.p, h->own_stats_all.p, (size_t)icm_stats_stride(h));
+    if (rc) return rc;
+    int fr = -1, code = 0;
+    if ((rc = icm_exchange_status(h, &fr, &code, nullptr))) return rc;
+    if (fr >= 0) FAIL(h, code, "sharded job: rank " + std::to_string(fr) + " failed behind the last sweep's exchange (" + phase_a_error_text(code) + ")");
+    return ICM_OK;
 }
 
 // Every rank's pose block -> every rank (before icm_get_state on a sharded handle).
@@ -2029,6 +2070,10 @@ int icm_gather_poses(icm_handle* h) {
     if (!h) return ICM_ERR_ARG;
     if (!h->comm_ready) FAIL(h, ICM_ERR_ARG, "icm_gather_poses: no communicator (icm_comm_init)");
     HIPCHK(h, hipSetDevice(h->device));
+    {
+        int rce = icm_sharded_end(h);   // (the closing exchange: a rank that failed behind the last sweep's exchange says so here)
+        if (rce) return rce;
+    }
     const size_t cnt = (size_t)h->comm_blk * 3;
     return all_gather(h, h->own_poses.p + (size_t)h->rank * cnt, h->own_poses.p, cnt);
 }
@@ -2102,7 +2147,9 @@ int icm_sweep(icm_handle* h, double* x, const double* x0, const double* map_in, 
         if ((rc = sync_host_map(h))) return rc;   // (already on the host: the last call returned it)
         fast = h->h_map.size() == 2 * (size_t)K && (K == 0 || std::memcmp(map_in, h->h_map.data(), 2 * (size_t)K * sizeof(double)) == 0);
     }
-    h->x_mirror = h->form == 0 ? xa : nullptr;
+    // (the even poses' lanes write the pairs (t - 1, t): a two-pose sequence has no even pose to solve, so nobody would
+    // write pose 1 into the caller's array -- it goes through the ordinary download)
+    h->x_mirror = (h->form == 0 && T >= 3) ? xa : nullptr;
     h->x_mirrored = false;
     h->host_map_wanted = true;
     if (fast) ++h->dropin_counts[0];
@@ -2583,7 +2630,7 @@ int icm_get_phase_times(const icm_handle* h, double* out5, int64_t* sweeps) {
 
 int icm_set_fault(icm_handle* h, int where) {
     if (!h) return ICM_ERR_ARG;
-    if (where < 0 || where > 1) FAIL(h, ICM_ERR_ARG, "icm_set_fault: 0 (none) or 1 (the next icm_sweep_local reports a HIP error)");
+    if (where < 0 || where > 2) FAIL(h, ICM_ERR_ARG, "icm_set_fault: 0 (none), 1 (the next icm_sweep_local reports a HIP error) or 2 (the next icm_sweep_targets does)");
     h->fault = where;
     return ICM_OK;
 }
@@ -2628,6 +2675,12 @@ int icm_set_gpu_filtrar(icm_handle* h, int on) {
 }
 
 // test hook: switch phase A to the brute-force (all landmarks, LDS-tiled) kernel
+int icm_get_wait_giveups(const icm_handle* h, int64_t* sweeps) {
+    if (!h || !sweeps) return ICM_ERR_ARG;
+    *sweeps = h->wait_giveups;
+    return ICM_OK;
+}
+
 int icm_set_assoc_form(icm_handle* h, int form) {
     if (!h || (form != 0 && form != 1)) return ICM_ERR_ARG;
     h->assoc_form = form;

@@ -2110,7 +2110,10 @@ __global__ __launch_bounds__(kBlock) void k_lm_l3(int nsuper, int L, int lact0, 
 
 // One wave on the side stream waits for a word to take a value (k_lm_l3's last workgroup: the raw map is out): what
 // is queued behind it starts then, a kernel boundary later.  Bounded (the launch that would set the word may have
-// failed): on giving up it raises *give_up, and Mapa.filtrar, queued behind, leaves the map alone (the sweep is repeated).
+// failed, or the streams may be serialised -- counter collection, HIP_LAUNCH_BLOCKING, two streams on one hardware queue --
+// so that the launch that sets the word cannot start while this one runs): on giving up it raises *give_up, Mapa.filtrar's
+// kernels, queued behind, leave the map alone, and the host runs Mapa.filtrar itself for this sweep (icm_sweep_finish:
+// correct, slower), counts the event (icm_get_wait_giveups) and starts the side stream by the stop event from then on.
 __global__ __launch_bounds__(kWave) void k_wait_word(const int* __restrict__ word, int value, int polls, int* __restrict__ give_up) {
     if (threadIdx.x != 0) return;
     for (int p = 0; p < polls; ++p) {

@@ -63,6 +63,7 @@ SIGNATURES = {
     "icm_comm_destroy": (C.c_int, [_H]),
     "icm_sweep_sharded": (C.c_int, [_H]),
     "icm_gather_poses": (C.c_int, [_H]),
+    "icm_sharded_end": (C.c_int, [_H]),
     "icm_set_optimistic": (C.c_int, [_H, C.c_int]),
     "icm_sweep_local": (C.c_int, [_H]),
     "icm_sweep_targets": (C.c_int, [_H]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "icm_kernel_time": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), _dp, _lp]),
     "icm_last_stats": (C.c_int, [_H, _lp]),
     "icm_set_brute_force": (C.c_int, [_H, C.c_int]),
+    "icm_get_wait_giveups": (C.c_int, [_H, _lp]),
     "icm_set_assoc_form": (C.c_int, [_H, C.c_int]),
     "icm_get_run_counts": (C.c_int, [_H, _lp]),
     "icm_get_runs": (C.c_int, [_H, _lp, _dp, _dp, C.POINTER(C.c_float), _ip, _ip]),

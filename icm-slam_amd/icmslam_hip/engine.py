@@ -348,7 +348,8 @@ class SweepEngine:
         return dict(zip(("local", "exchange", "targets", "solve", "finish_host_wait"), (out / k).round(4).tolist())), int(n.value)
 
     def set_fault(self, where):
-        """Test hook: 1 = the next sweep_local fails like a HIP error (icm_set_fault)."""
+        """Test hook: 1 = the next sweep_local fails like a HIP error, 2 = the next sweep_targets does -- behind the
+        sweep's exchange (icm_set_fault)."""
         self._chk(self.lib.icm_set_fault(self.h, int(where)))
 
     def sweep_solve(self, schedule="redblack", colour=-1):
@@ -444,6 +445,11 @@ class SweepEngine:
 
     def gather_poses(self):
         self._chk(self.lib.icm_gather_poses(self.h))
+
+    def sharded_end(self):
+        """The closing exchange of a sharded job driven by the library (icm_sharded_end): raises the error of a rank that
+        failed behind the last sweep's exchange.  gather_poses() runs it first."""
+        self._chk(self.lib.icm_sharded_end(self.h))
 
     # ---- inspection ----------------------------------------------------------------------
     def association(self):
@@ -574,6 +580,12 @@ class SweepEngine:
 
     def set_brute_force(self, on):
         self._chk(self.lib.icm_set_brute_force(self.h, int(bool(on))))
+
+    def wait_giveups(self):
+        """Sweeps whose side-stream wait for the raw map gave up (serialised streams): 0 in a normal run."""
+        n = C.c_int64(0)
+        self._chk(self.lib.icm_get_wait_giveups(self.h, C.byref(n)))
+        return int(n.value)
 
     def set_assoc_form(self, form):
         """What phase A associates: 1 / 'runs' (default) geometric runs of each scan's kept beams, settled by the

@@ -139,9 +139,22 @@ class ShardedSweep:
                     continue
             elif err is not None:
                 raise err
-            e.sweep_targets()
-            e.sweep_solve("redblack", -1)           # both colours, ghost pose included, one launch
-            if not e.sweep_finish():
+            try:
+                e.sweep_targets()
+                e.sweep_solve("redblack", -1)       # both colours, ghost pose included, one launch
+                again = e.sweep_finish()
+            except (IndexError, RuntimeError, ValueError):
+                # Failing together BEHIND the exchange: the peers' phases ran and they are on their way to the next exchange
+                # (the next sweep's, or the closing one of end() / get_state()).  Meet them there with the code in the
+                # header -- a farewell message -- so that they raise too instead of waiting for a rank that has left.
+                if hasattr(e, "mark_failed") and getattr(e, "last_rc", 0) < 0 and not isinstance(self.comm, NoComm):
+                    try:
+                        e.mark_failed(e.last_rc)
+                        self.comm.gather_stats(self)
+                    except Exception:
+                        pass
+                raise
+            if not again:
                 break
             if status is not None:
                 # before the repeated sweep's collective: a rank that FAILED in this one has left with its error and will
@@ -153,8 +166,23 @@ class ShardedSweep:
         if can:
             e.set_optimistic(False)
 
+    def end(self):
+        """The closing exchange: every rank calls it once after its last sweep (get_state does).  One more all-gather of
+        the statistics message with a clean header; a rank that failed behind the last sweep's exchange delivers its
+        error here, and every rank raises it."""
+        e = self.eng
+        if isinstance(self.comm, NoComm) or not hasattr(e, "mark_failed") or not hasattr(e, "exchange_status"):
+            return
+        e.mark_failed(0)
+        self.comm.gather_stats(self)
+        fr, code, _ = e.exchange_status()
+        if fr >= 0:
+            from .engine import _raise
+            _raise(code, "sharded job: rank %d failed behind the last sweep's exchange" % fr)
+
     def get_state(self):
-        """(x, map, counts, K) of the whole sequence: gathers the pose blocks first."""
+        """(x, map, counts, K) of the whole sequence: the closing exchange, then the pose blocks are gathered."""
+        self.end()
         self.comm.all_gather(self.poses, self.rank, self.blk * 3)
         return self.eng.get_state()
 
@@ -187,6 +215,10 @@ class LibrarySweep:
         if schedule != "redblack":
             raise NotImplementedError("only the red-black schedule shards (the reference order is one chain)")
         self.eng.sweep_sharded()
+
+    def end(self):
+        """The closing exchange (icm_sharded_end); get_state() runs it itself."""
+        self.eng.sharded_end()
 
     def get_state(self):
         self.eng.gather_poses()

@@ -181,6 +181,14 @@ int icm_comm_init_transport(icm_handle *h, int rank, int world, icm_allgather_fn
 int icm_comm_destroy(icm_handle *h);
 int icm_sweep_sharded(icm_handle *h);
 int icm_gather_poses(icm_handle *h);
+/* Failing together BEHIND a sweep's exchange (a device error in the targets, the solve launch or Mapa.filtrar of one rank,
+ * while its peers' phases ran and they are on their way to the next exchange): icm_sweep_sharded on that rank sends one
+ * more message -- its header carrying the code, nothing else -- which the peers receive as their NEXT exchange: the next
+ * sweep's, or the closing exchange icm_sharded_end, which every rank of a job calls once after its last sweep
+ * (icm_gather_poses runs it first).  Every rank then returns that rank's error, one exchange later; nobody waits for a
+ * rank that has left.  A rank that cannot send at all aborts the communicator (RCCL: ncclCommAbort; with a
+ * caller-supplied transport the peers are left to that transport's own timeout). */
+int icm_sharded_end(icm_handle *h);
 /* Phase calls only (icm_sweep_device / icm_sweep / icm_sweep_sharded do this themselves): queue the sweep whole, without
  * the host looking at phase A's counts and overflow flags in the middle -- solves and Mapa.filtrar check the flags on
  * the device (on every rank: the flags travel in the header of the statistics message); icm_sweep_finish then returns
@@ -198,7 +206,7 @@ int icm_sweep_finish(icm_handle *h);                  /* Mapa.filtrar, next mapa
  * the collective: it calls icm_mark_failed(h, code) -- its message then carries the code in header [1] -- and takes
  * part in the exchange; after it, EVERY rank calls icm_failed_rank and stops if some rank failed (*rank_out >= 0,
  * *code_out its ICM_ERR_* code).  icm_sweep_sharded does both itself. */
-int icm_mark_failed(icm_handle *h, int code);
+int icm_mark_failed(icm_handle *h, int code);   /* code 0: a clean header (the closing exchange of callers that issue the collectives themselves) */
 int icm_failed_rank(icm_handle *h, int *rank_out, int *code_out);
 /* The same look at every rank's header, plus *retry_out = 1 when some rank reports flags of a sweep it had queued whole
  * (header [1] == 1): that rank and every rank that queued the sweep whole will repeat it (ICM_RETRY_CAREFUL from their

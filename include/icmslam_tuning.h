@@ -34,6 +34,17 @@ int icm_get_run_counts(icm_handle *h, int64_t *out2);
  * first beam among the pose's kept beams.  Sized by icm_get_run_counts()[0]; any pointer may be NULL. */
 int icm_get_runs(icm_handle *h, int64_t *offsets, double *centre_xy, double *sum_xy, float *radius, int32_t *count, int32_t *first);
 
+/* Sweeps queued whole start Mapa.filtrar on a side stream the moment the raw map is out: a one-wave kernel there polls a
+ * word the main stream's k_lm_l3 sets (no event packet on the main queue).  Where the two streams cannot run side by side
+ * (counter collection with rocprofv3 --pmc, HIP_LAUNCH_BLOCKING / AMD_SERIALIZE_KERNEL, more streams than hardware queues)
+ * the wait gives up after ~16 ms, that sweep's Mapa.filtrar runs on the host (same result), and the handle switches to a
+ * stop event for the rest of its life.  icm_get_wait_giveups: how many sweeps that happened to (0 in a normal run; a
+ * profile taken under serialisation shows the event path from the second sweep on). */
+int icm_get_wait_giveups(const icm_handle *h, int64_t *sweeps);
+/* Environment knobs read once at icm_create (A/B measurements; results identical): ICM_L3_EVENT=1 starts the side stream
+ * by k_lm_l3's stop event from the first sweep (what a give-up switches to); ICM_SOLVE_PPW=32|64 fixes the poses per wave
+ * of the one-launch solve (default: 64, 32 for short colours). */
+
 /* Keep the per-beam outputs of a sweep (label and running-mean target of every kept beam)
  * for icm_get_association; off by default (they cost 28 B of HBM traffic per kept beam). */
 int icm_set_debug(icm_handle *h, int on);
@@ -95,7 +106,9 @@ int icm_set_phase_timing(icm_handle *h, int on);
 int icm_get_phase_times(const icm_handle *h, double *out5, int64_t *sweeps);
 
 /* Test hook: where = 1 makes the next icm_sweep_local fail with ICM_ERR_HIP before it launches anything (a rank of a
- * sharded job whose device failed: it must still take part in the sweep's collective, icm_sweep_sharded); 0 = off. */
+ * sharded job whose device failed: it must still take part in the sweep's collective, icm_sweep_sharded); where = 2 makes
+ * the next icm_sweep_targets fail the same way -- BEHIND the sweep's exchange, where the peers no longer wait for this
+ * rank in this sweep (icm_sharded_end); 0 = off. */
 int icm_set_fault(icm_handle *h, int where);
 
 /* Sizes of the staging area of phase A's (pose, landmark) entries for a shard with nnz kept beams and nloc poses (host

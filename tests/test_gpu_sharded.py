@@ -438,6 +438,91 @@ def _protocol_worker_entry(rank, world, port, out_path, driver, case):
         _protocol_worker(rank, world, port, out_path, driver, case)
 
 
+def _post_exchange_worker(rank, world, port, out_path, driver, then):
+    """One rank of a three-process job in which rank 1 fails BEHIND a sweep's exchange (icm_set_fault(2): its
+    icm_sweep_targets reports a device error while its peers' phases run to the end).  `then` = what the peers do next:
+    "sweep" -- another sweep; "end" -- the closing exchange (get_state).  Rank 1 must come back with its error, and the
+    peers with the same error at their next exchange; nobody may hang."""
+    import ctypes
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "icm-slam_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.sharded import LibrarySweep, ShardedSweep, TorchComm, partition
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from util import hip_runtime
+
+    class HostHopComm(TorchComm):
+        def _ag(self, out, inp):
+            o, i = out.cpu(), inp.cpu()
+            self.dist.all_gather_into_tensor(o, i, group=self.group)
+            out.copy_(o)
+
+        def gather_stats(self, sw):
+            self._ag(sw.stats, sw.stats_send)
+
+        def all_gather(self, buf, r, count):
+            self._ag(buf, buf[r * count:(r + 1) * count].clone())
+
+    def gloo_transport(send_ptr, recv_ptr, count, stream_ptr):
+        hip = hip_runtime()
+        assert hip.hipStreamSynchronize(ctypes.c_void_p(stream_ptr)) == 0
+        mine = torch.empty(count, dtype=torch.float64)
+        allr = torch.empty(count * world, dtype=torch.float64)
+        assert hip.hipMemcpy(ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(send_ptr), ctypes.c_size_t(8 * count), 2) == 0
+        dist.all_gather_into_tensor(allr, mine)
+        assert hip.hipMemcpy(ctypes.c_void_p(recv_ptr), ctypes.c_void_p(allr.data_ptr()), ctypes.c_size_t(8 * count * world), 1) == 0
+
+    wl, cfg = _workload()
+    _, parts = partition(wl.T, world)
+    a, b = parts[rank]
+    e = SweepEngine(cfg)
+    e.upload(wl.scans[a:b], wl.odometry, wl.u, t_begin=a, t_end=b, pose_major=True, ghost_scan=wl.scans[a - 1] if a else None)
+    run = LibrarySweep(e, rank, world, wl.T, transport=gloo_transport) if driver == "library" else ShardedSweep(e, rank, world, wl.T, comm=HostHopComm())
+    run.set_state(wl.map_init, wl.x_init, wl.x0)
+    run.sweep("redblack")             # a clean sweep first
+    if rank == 1:
+        e.set_fault(2)
+    log = []
+    try:
+        run.sweep("redblack")         # rank 1 fails behind this sweep's exchange; its peers finish the sweep
+        log.append("sweep ok")
+        if then == "sweep":
+            run.sweep("redblack")     # the peers' next exchange: rank 1's farewell
+            log.append("next sweep ok")
+        else:
+            run.get_state()           # ... or the closing exchange
+            log.append("end ok")
+    except (IndexError, RuntimeError) as ex:
+        log.append("%s: %s" % (type(ex).__name__, ex))
+    open(out_path % rank, "w").write(" | ".join(log))
+    e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("driver,then,port", [("library", "sweep", 29641), ("torch", "sweep", 29651), ("library", "end", 29661), ("torch", "end", 29671)])
+def test_a_rank_that_fails_behind_the_exchange_takes_every_rank_with_it(tmp_path, driver, then, port):
+    """A device error in one rank's icm_sweep_targets -- behind the sweep's one collective, where its peers no longer
+    depend on it in this sweep (scripts/ICM_ROS.py:141-158 sharded) -- must still end every rank: the failing rank sends a
+    farewell message into the peers' NEXT exchange (the next sweep's, or the closing one) and every rank raises its error
+    there.  Round 4 left the peers waiting in the next sweep's all-gather."""
+    import torch.multiprocessing as mp
+    world = 3
+    out = str(tmp_path / "rank%d.txt")
+    mp.spawn(_post_exchange_worker, args=(world, port, out, driver, then), nprocs=world, join=True)
+    res = [open(out % r).read() for r in range(world)]
+    print(driver, then, res)
+    assert res[1].startswith("IcmError: icmslam_hip error -2"), res          # the failing rank: its own error, at once
+    for r in (0, 2):
+        assert res[r].startswith("sweep ok | IcmError: icmslam_hip error -2"), res   # the peers: one exchange later
+
+
 def _nobeam_worker(rank, world, port, out_path, driver):
     """case "nobeam" of _protocol_worker without the clean sweep in front (the last pose never has beams)."""
     import ctypes

@@ -317,3 +317,124 @@ def test_dataset_driver_loop_in_reference_order_with_a_registered_array(icm):
         g = gold("sweep%02d.npz" % (1 if it == 2 else it + 1))
         assert np.abs(mapa_refinado - g["mapa"]).max() <= 1e-9 and np.abs(x - g["x"]).max() <= 1e-9
         mapa_viejo = copy(mapa_refinado)
+
+
+def test_in_place_edits_of_the_sequence_and_invalidate_sequence():
+    """The reference re-reads `mediciones` on every call (scripts/ICM_ROS.py:142); here the sequence is uploaded and
+    pre-filtered once and its identity is a sampled checksum: replacing the array or editing a sampled
+    column re-uploads by itself, an edit of an unsampled column must be announced with invalidate_sequence() -- and is
+    then honoured exactly (the result equals a fresh object's on the edited data)."""
+    from ICM_ROS import ICM_ROS
+    from ICM_SLAM_tools import ConfigICM
+    init = gold("init_pass.npz")
+
+    def fresh(med=None):
+        m = ICM_ROS(ConfigICM("config_default.yaml"))
+        m.load_data(os.path.join(GOLD, "data_IJAC2018.npz"))
+        if med is not None:
+            m.mediciones = med
+        m.set_initial_state(init["x_init"], init["map_init"], init["cant_obs_i"])
+        return m
+
+    def sweep(m):
+        m.set_initial_state(init["x_init"], init["map_init"], init["cant_obs_i"])
+        mv, x = copy(m.mapa_viejo), copy(m.positions)
+        return m.iterations_process_offline(mv, x)
+
+    m = fresh()
+    base_map, base_x = sweep(m)
+    T = m.mediciones.shape[1]
+    step = max(1, T // 16)
+    unsampled = next(t for t in range(700, T) if t % step and t != T - 1)
+    edited = m.mediciones.copy()
+    edited[:, unsampled] = m.config.rango_laser_max        # that scan loses all its beams
+    want_map, want_x = sweep(fresh(edited))
+    assert np.abs(want_x - base_x).max() > 1e-6             # the edit matters
+    # in place, unsampled column: not noticed (the documented difference) ...
+    m.mediciones[:, unsampled] = m.config.rango_laser_max
+    got_map, got_x = sweep(m)
+    assert np.array_equal(got_x, base_x)
+    # ... until announced
+    m.invalidate_sequence()
+    got_map, got_x = sweep(m)
+    assert np.array_equal(got_x, want_x) and np.array_equal(got_map, want_map)
+    # a sampled column (the last one is always sampled), in place: noticed by itself
+    m2 = fresh()
+    sweep(m2)
+    m2.mediciones[:, 0] = m2.mediciones[:, 1]
+    ed2 = m2.mediciones.copy()
+    w_map, w_x = sweep(fresh(ed2))
+    g_map, g_x = sweep(m2)
+    assert np.array_equal(g_x, w_x) and np.array_equal(g_map, w_map)
+    # a replaced array: noticed by itself
+    m3 = fresh()
+    sweep(m3)
+    m3.mediciones = edited.copy()
+    g_map, g_x = sweep(m3)
+    assert np.array_equal(g_x, want_x)
+
+
+def test_two_pose_sequence_through_the_drop_in_call_on_a_registered_array():
+    """T = 2 (icm_upload's minimum): there is no even pose whose lane would mirror the pair (1, 2) into a registered host
+    array, so the call must hand pose 1 back through the ordinary download -- call after call on the same array."""
+    from ICM_SLAM_tools import ConfigICM
+    from icmslam_hip import SweepEngine
+    from icmslam_hip.synthetic import make_workload
+    wl = make_workload(700, 64, 180)
+    cfg = ConfigICM(D=wl.config)
+    cfg.cota = 1.0
+    sl = slice(0, 2)
+    x = np.ascontiguousarray(wl.x_init[:, sl]).copy()
+    eng = SweepEngine(cfg)
+    eng.upload(wl.scans[sl], wl.odometry[:, sl], wl.u[:, sl], pose_major=True)
+    ref = SweepEngine(cfg)
+    ref.upload(wl.scans[sl], wl.odometry[:, sl], wl.u[:, sl], pose_major=True)
+    m = wl.map_init.copy()
+    K = m.shape[1]
+    for call in range(4):
+        xr = x.copy()
+        mo_r, co_r, K_r = ref.sweep(m[:, :K], xr, wl.x0, K, "redblack")       # a fresh copy every call: never registered
+        mo, co, K2 = eng.sweep(m[:, :K], x, wl.x0, K, "redblack")             # the same array every call: registered from the second
+        assert K2 == K_r and np.array_equal(x, xr), "call %d" % call
+        assert np.array_equal(mo, mo_r)
+        assert not np.array_equal(x[:, 1], wl.x_init[:, 1])                   # pose 1 was solved and came back
+        m, K = mo, K2
+    eng.close()
+    ref.close()
+
+
+def test_serialised_streams_make_the_side_stream_wait_give_up_once():
+    """With HIP_LAUNCH_BLOCKING=1 no two launches overlap: the one-wave kernel that polls for the raw map on the side stream
+    (k_wait_word) can never see the word the main stream's next launch would set.  It must give up (bounded), that sweep's
+    Mapa.filtrar then runs on the host, the handle switches to the stop event for good -- ONE give-up however many sweeps --
+    and every sweep's result equals an ordinary run's."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, zlib
+sys.path.insert(0, "icm-slam_amd"); sys.path.insert(0, ".")
+import numpy as np
+from ICM_SLAM_tools import ConfigICM
+from icmslam_hip import SweepEngine
+from icmslam_hip.synthetic import WORKLOADS, make_workload
+wl = make_workload(*WORKLOADS["tiny"])
+eng = SweepEngine(ConfigICM(D=wl.config))
+eng.upload(wl.scans, wl.odometry, wl.u, pose_major=True)
+eng.set_state(wl.map_init, wl.x_init, wl.x0)
+for _ in range(4):
+    eng.sweep_device("redblack")
+x, m, c, K = eng.get_state()
+print("RESULT", eng.wait_giveups(), K, zlib.crc32(x.tobytes()), zlib.crc32(m.tobytes()))
+eng.close()
+'''
+    root = os.path.dirname(GOLD.rstrip("/")).rsplit("/tests", 1)[0]
+    outs = {}
+    for blocking in ("0", "1"):
+        env = dict(os.environ, HIP_LAUNCH_BLOCKING=blocking)
+        p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")]
+        assert p.returncode == 0 and line, p.stderr[-2000:]
+        outs[blocking] = line[0].split()[1:]
+    assert outs["0"][0] == "0", "an ordinary run never gives up"
+    assert outs["1"][0] == "1", "serialised streams: one give-up, then the event path (got %s)" % outs["1"][0]
+    assert outs["0"][1:] == outs["1"][1:], "same map and poses either way"
