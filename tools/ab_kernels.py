@@ -26,5 +26,5 @@ for mode in [int(a) for a in sys.argv[1:]] or [0, 1]:
     kt = eng.kernel_times(); eng.enable_timing(False)
     x = eng.get_state()[0]
     if ref is None: ref = x
-    print(os.environ.get("VLIB", "default"), "lanes-mode", mode, "ms/sweep %.4f" % ms, "k_solve", kt.get("k_solve"), "k_assoc", kt.get("k_assoc_group"), "l1", round(kt["k_chunk_l1"][0]/kt["k_chunk_l1"][1],4), "moments", round(kt["k_pose_moments"][0]/kt["k_pose_moments"][1],4), "l2/l3/push", [round(kt[k][0]/kt[k][1],4) for k in ("k_chunk_l2","k_lm_l3","k_rec_push")], "same", bool(np.array_equal(x, ref)), "crc %08x" % zlib.crc32(np.ascontiguousarray(x).tobytes()), flush=True)
+    print(os.environ.get("VLIB", "default"), "lanes-mode", mode, "ms/sweep %.4f" % ms, "k_solve", kt.get("k_solve"), "k_assoc", round(sum(kt[k][0] / kt[k][1] for k in ("k_assoc_group", "k_assoc_runs") if kt.get(k, (0, 0))[1]), 4), "l1", round(kt["k_chunk_l1"][0]/kt["k_chunk_l1"][1],4), "moments", round(kt["k_pose_moments"][0]/kt["k_pose_moments"][1],4), "l2/l3/push", [round(kt[k][0]/kt[k][1],4) for k in ("k_chunk_l2","k_lm_l3","k_rec_push")], "same", bool(np.array_equal(x, ref)), "crc %08x" % zlib.crc32(np.ascontiguousarray(x).tobytes()), flush=True)
 eng.close()
