@@ -1,7 +1,7 @@
 # rocprofv3 passes behind profiles/rNN_*: run on the GPU box from the repo root (copy gpurun_out/TAG_* and gpurun_out/traffic.json into profiles/ afterwards),
 #   gpurun -- 'bash tools/profile.sh TAG'
 # kernel-trace/stats and the PMC passes are separate runs (the pool refuses them combined).
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --workload S2 --steps 6 --warmup 2 --cpu-poses 0 --no-roofline --no-extras"
 O=gpurun_out/prof_$TAG
@@ -22,3 +22,6 @@ cp profiles/traffic.json gpurun_out/traffic.json 2>/dev/null
 python3 tools/pmc_summary.py --traffic gpurun_out/traffic.json S2 gpurun_out/${TAG}_pmc_traffic_S2.csv $BID > /dev/null
 sed -i "s#profiles/${TAG}_pmc_traffic_S2.csv#profiles/${TAG}_pmc_traffic_S2.csv#" gpurun_out/traffic.json
 echo "build $BID"
+# one steady-state sweep on every queue (from the stats pass's kernel trace)
+python3 tools/sweep_timeline.py $O/stats > gpurun_out/${TAG}_sweep_timeline_S2.txt 2>&1
+head -40 gpurun_out/${TAG}_sweep_timeline_S2.txt

@@ -9,7 +9,7 @@ f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if "k_assoc_group<false, false" in n]
+idx = [i for i, n in enumerate(names) if "k_assoc_runs<false" in n or "k_assoc_group<false, false" in n]
 i0, i1 = idx[40], idx[41]
 t0 = int(rows[i0]["Start_Timestamp"])
 print("sweep period: %.1f us" % ((int(rows[i1]["Start_Timestamp"]) - t0) / 1e3))
