@@ -296,6 +296,10 @@ class Job:
         sys.stderr.flush()
 
     def close(self):
+        # a sharded job ends with the closing exchange (every rank, same place): where a rank that failed behind the last
+        # sweep's exchange delivers its error instead of leaving its peers waiting (icm_sharded_end)
+        if getattr(self, "sharded", False) and hasattr(getattr(self, "runner", None), "end"):
+            self.runner.end()
         if hasattr(getattr(self, "runner", None), "close"):
             self.runner.close()
         if hasattr(self.eng, "close"):
