@@ -66,10 +66,11 @@ def algorithmic_bytes(kernel, nnz, E, nloc, L, nlaunch, hier=True, runs=0):
         # read body x,y of every kept beam (16 B) + pose; write one staged entry
         # (label 4, k 2, sum bx 8, sum by 8) per distinct landmark of the scan; counts/flags
         "k_assoc_group": nnz * 16 + E * 22 + nloc * (24 + 8 + 8),
-        # phase A by runs: one 40-B record per run (centre 16, sum of body points 16, radius 4, count | first beam 4) in --
-        # no beam is read where the bounding-circle test settles the run (S2: every run) --, one staged entry (22) per
-        # distinct landmark of the scan out; per pose: pose 24, rotation pair 16, run / beam / plan offsets 12, counts 12
-        "k_assoc_runs": runs * 40 + E * 22 + nloc * (24 + 16 + 12 + 12),
+        # phase A by runs: one 24-B record per run (sum of body points 16 -- the circle's centre is that sum / count --, radius
+        # 4, count | first beam 4) in -- no beam is read where the bounding-circle test settles the run (S2: every run) --, one
+        # staged entry (22) per distinct landmark of the scan out; per pose: pose 24, rotation pair 16, run / beam / plan
+        # offsets 12, counts 12
+        "k_assoc_runs": runs * 24 + E * 22 + nloc * (24 + 16 + 12 + 12),
         "k_associate_brute": nnz * (16 + 4) + nloc * 32,
         # staged entries in (22); out: key 4, id 4, k 4, world sums 32, rotated mean offset 16;
         # per pose: pose 24, second moments 24, scatter 24, offsets 8

@@ -91,7 +91,7 @@ struct icm_handle {
     int64_t nnz = 0;
     // geometric runs of the kept beams (k_run_build, once per sequence): what phase A associates (k_assoc_runs)
     DevBuf<int> nrun, roff, gh_roff;
-    DevBuf<double2> r_c, r_s, gh_rc, gh_rs;   // bounding-circle centre (body frame) | sum of the run's body points
+    DevBuf<double2> r_s, gh_rs;               // sum of the run's body points (the bounding circle's centre is sum / k)
     DevBuf<uint2> r_m, gh_rm;                 // radius (float bits, rounded up) | beams | first beam's offset in the pose << 16
     int64_t nruns = 0;
     int assoc_form = 1;                       // 1 by runs (k_assoc_runs), 0 beam by beam (k_assoc_group): icm_set_assoc_form
@@ -639,19 +639,19 @@ static int reserve_map_buffers(icm_handle* h) {
 // 0.5 dist_thr from the run's first one (a trunk's visible arc is one run; a hedge is cut into pieces small enough
 // for the bounding-circle test of k_assoc_runs to settle them).
 static int build_runs(icm_handle* h, const int* boff, const double2* bxy, int nloc, DevBuf<int>& nrun, DevBuf<int>& roff,
-                      DevBuf<double2>& r_c, DevBuf<double2>& r_s, DevBuf<uint2>& r_m, int64_t* nruns_out) {
+                      DevBuf<double2>& r_s, DevBuf<uint2>& r_m, int64_t* nruns_out) {
     const double thr = h->cfg.dist_thr > 0.0 ? h->cfg.dist_thr : 1.0;
     const double gap = 0.35 * thr, ext = 0.5 * thr;
     HIPCHK(h, nrun.reserve((size_t)nloc + 1));
     HIPCHK(h, roff.reserve((size_t)nloc + 1));
-    TIMED(h, KID_RUN_BUILD, (k_run_build<false><<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(boff, bxy, nloc, gap * gap, ext * ext, nrun.p, nullptr, nullptr, nullptr, nullptr)));
+    TIMED(h, KID_RUN_BUILD, (k_run_build<false><<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(boff, bxy, nloc, gap * gap, ext * ext, nrun.p, nullptr, nullptr, nullptr)));
     k_exscan_i32<<<1, 1024, 0, h->stream>>>(nrun.p, roff.p, nloc);
     int total = 0;
     HIPCHK(h, hipMemcpyAsync(&total, roff.p + nloc, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t nr = (size_t)std::max(total, 1);
-    HIPCHK(h, r_c.reserve(nr)); HIPCHK(h, r_s.reserve(nr)); HIPCHK(h, r_m.reserve(nr));
-    TIMED(h, KID_RUN_BUILD, (k_run_build<true><<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(boff, bxy, nloc, gap * gap, ext * ext, nullptr, roff.p, r_c.p, r_s.p, r_m.p)));
+    HIPCHK(h, r_s.reserve(nr)); HIPCHK(h, r_m.reserve(nr));
+    TIMED(h, KID_RUN_BUILD, (k_run_build<true><<<nblocks_threads(nloc), kBlock, 0, h->stream>>>(boff, bxy, nloc, gap * gap, ext * ext, nullptr, roff.p, r_s.p, r_m.p)));
     HIPCHK(h, hipGetLastError());
     if (nruns_out) *nruns_out = total;
     return ICM_OK;
@@ -689,7 +689,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     TIMED(h, KID_PREFILTER, (k_prefilter<true><<<nb, kBlock, lds, h->stream>>>(h->ranges.p, h->cosb.p, h->sinb.p, nloc, B, h->cfg.rango_laser_max, h->cfg.dist_thr, nullptr, h->boff.p, h->bk.p, h->bd.p, h->bx.p, h->by.p, h->pose_s2.p, h->bxy.p, h->thr2, h->kmask.p)));
     // the geometric runs of every scan (k_assoc_runs associates runs, not beams): counted, scanned, filled
     {
-        int rr = build_runs(h, h->boff.p, h->bxy.p, nloc, h->nrun, h->roff, h->r_c, h->r_s, h->r_m, &h->nruns);
+        int rr = build_runs(h, h->boff.p, h->bxy.p, nloc, h->nrun, h->roff, h->r_s, h->r_m, &h->nruns);
         if (rr) return rr;
         HIPCHK(h, h->run_counts.reserve(2));
         HIPCHK(h, hipMemsetAsync(h->run_counts.p, 0, 2 * sizeof(unsigned long long), h->stream));
@@ -762,7 +762,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
         h->ghost_n = gb[1];
         {
             DevBuf<int> gnr;   // (the ghost's run count: scratch)
-            int rr = build_runs(h, h->gh_boff.p, h->gh_bxy.p, 1, gnr, h->gh_roff, h->gh_rc, h->gh_rs, h->gh_rm, nullptr);
+            int rr = build_runs(h, h->gh_boff.p, h->gh_bxy.p, 1, gnr, h->gh_roff, h->gh_rs, h->gh_rm, nullptr);
             gnr.release();
             if (rr) return rr;
         }
@@ -1114,7 +1114,7 @@ int icm_sweep_local(icm_handle* h) {
 #define ASSOC_GROUP_HS(PRE, DBG) do { if (h->hash_slots == 128) ASSOC_GROUP(PRE, DBG, 128); else ASSOC_GROUP(PRE, DBG, 256); } while (0)
     const float thr_margin = (float)(1e-4 * h->cfg.dist_thr), thr_m = (float)h->cfg.dist_thr - thr_margin;
 #define ASSOC_RUNS(DBG, HS) TIMED(h, KID_ASSOC_RUNS, (k_assoc_runs<DBG, HS><<<nblocks_waves(nloc), kBlock, 0, h->stream>>>( \
-        h->x, h->roff.p, h->r_c.p, h->rot.p, h->gpar.p, h->ent_off.p, nloc, (int)h->t_begin, h->x0.p, h->r_s.p, h->r_m.p, h->boff.p, h->bxy.p, gv, \
+        h->x, h->roff.p, h->r_s.p, h->rot.p, h->gpar.p, h->ent_off.p, nloc, (int)h->t_begin, h->x0.p, h->r_m.p, h->boff.p, h->bxy.p, gv, \
         h->cfg.dist_thr, h->thr2, thr_m, thr_margin, h->label.p, h->bloc.p, h->st_label.p, h->st_k.p, h->st_sx.p, h->st_sy.p, h->nent.p, h->isnew.p, h->fl, \
         (int)h->nnz, h->st_off.p, 0, (int)h->stl.sparse0, h->run_counts.p)))
 #define ASSOC_RUNS_HS(DBG) do { if (h->hash_slots == 128) ASSOC_RUNS(DBG, 128); else ASSOC_RUNS(DBG, 256); } while (0)
@@ -1275,8 +1275,8 @@ static int launch_ghost(icm_handle* h) {
     HIPCHK(h, hipMemsetAsync(gm + 8, 0, 16 * sizeof(int), gs));
     if (h->assoc_form == 1) {   // (the form its owner's rank uses: the ghost's entries carry the owner's sums bit for bit)
         const float thr_margin = (float)(1e-4 * h->cfg.dist_thr), thr_m = (float)h->cfg.dist_thr - thr_margin;
-        k_assoc_runs<false, 256><<<1, kBlock, 0, gs>>>(h->x, h->gh_roff.p, h->gh_rc.p, h->gh_rot.p, h->gpar.p, gm + 3, 1, (int)h->t_begin - 1, h->x0.p,
-            h->gh_rs.p, h->gh_rm.p, h->gh_boff.p, h->gh_bxy.p, GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p}, h->cfg.dist_thr, h->thr2, thr_m, thr_margin,
+        k_assoc_runs<false, 256><<<1, kBlock, 0, gs>>>(h->x, h->gh_roff.p, h->gh_rs.p, h->gh_rot.p, h->gpar.p, gm + 3, 1, (int)h->t_begin - 1, h->x0.p,
+            h->gh_rm.p, h->gh_boff.p, h->gh_bxy.p, GridView{h->gpar.p, h->g_cell.p, h->g_lm.p, h->g_nb.p}, h->cfg.dist_thr, h->thr2, thr_m, thr_margin,
             h->gh_label.p, h->gh_bloc.p, h->gh_st_label.p, h->gh_st_k.p, h->gh_sx.p, h->gh_sy.p, gm, gm + 1, gm + 8, h->ghost_n, gm + 2, 0, kWave, nullptr);
     } else
     k_assoc_group<false, false, 256><<<1, kBlock, 0, gs>>>(h->x, h->gh_boff.p, h->gh_bxy.p, h->gh_rot.p, h->gpar.p, gm + 3, 1, (int)h->t_begin - 1, h->x0.p,
@@ -2711,12 +2711,18 @@ int icm_get_runs(icm_handle* h, int64_t* offsets, double* centre_xy, double* sum
         for (size_t i = 0; i <= nloc; ++i) offsets[i] = ro[i];
     }
     if (nr) {
-        if (centre_xy) HIPCHK(h, hipMemcpy(centre_xy, h->r_c.p, nr * sizeof(double2), hipMemcpyDeviceToHost));
+        std::vector<double> sums;
+        if (centre_xy && !sum_xy) { sums.resize(2 * nr); sum_xy = sums.data(); }
         if (sum_xy) HIPCHK(h, hipMemcpy(sum_xy, h->r_s.p, nr * sizeof(double2), hipMemcpyDeviceToHost));
-        if (radius || count || first) {
+        if (radius || count || first || centre_xy) {
             std::vector<uint2> m(nr);
             HIPCHK(h, hipMemcpy(m.data(), h->r_m.p, nr * sizeof(uint2), hipMemcpyDeviceToHost));
             for (size_t i = 0; i < nr; ++i) {
+                if (centre_xy) {   // (not stored: the same division the kernels make)
+                    const double kd = (double)(m[i].y & 0xffffu);
+                    centre_xy[2 * i] = sum_xy[2 * i] / kd;
+                    centre_xy[2 * i + 1] = sum_xy[2 * i + 1] / kd;
+                }
                 if (radius) std::memcpy(&radius[i], &m[i].x, sizeof(float));
                 if (count) count[i] = (int32_t)(m[i].y & 0xffffu);
                 if (first) first[i] = (int32_t)(m[i].y >> 16);

@@ -1054,7 +1054,7 @@ void k_assoc_group(const double* __restrict__ x, const int* __restrict__ boff, c
 // is a per-beam rule, but its outcome is almost always the same for every beam of a small cluster of neighbouring
 // returns (one trunk): 6.3 beams share a label on S2.  A geometric RUN is a stretch of consecutive kept beams of one
 // scan whose body-frame points lie close together -- a function of the scan alone, so it is cut ONCE per sequence, beside
-// filtrar_z (k_run_build), with its bounding circle (centre c, radius r), beam count k and sum of body points.  Per
+// filtrar_z (k_run_build), with its sum of body points, beam count k and bounding circle (centre c = sum / k, radius r).  Per
 // sweep ONE lane per run projects the centre with the pose's previous-sweep value (tras_rot_z, :465-480, is a rigid
 // motion: every beam's world point stays within r of the centre's), reads ONE grid record and takes the nearest
 // candidate i1 at distance d1 and the second nearest at d2.  With cell >= dist_thr the edge of the search grid:
@@ -1072,13 +1072,15 @@ constexpr int kRunUndecided = -3;
 
 // One thread per pose cuts its kept beams into runs: a new run starts where the next body point is farther than `gap`
 // from the last one, farther than `ext` from the run's first point, or after kRunCap beams.  FILL = false counts the
-// runs (nrun), FILL = true writes them at roff[t]: centre = mean of the body points, radius = largest distance to it
-// rounded UP into a float, k | first beam's offset within the pose << 16, sum of the body points in beam order.
+// runs (nrun), FILL = true writes them at roff[t]: sum of the body points in beam order (the circle's centre is their mean,
+// sum / k: formed again by k_assoc_runs with the same division, not stored -- 24 instead of 40 bytes per run through a
+// kernel bound by its memory path, -3.5 %), radius = largest distance to the centre rounded UP into a float, k | first
+// beam's offset within the pose << 16.
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_run_build(const int* __restrict__ boff, const double2* __restrict__ bxy, int nloc,
                                                       double gap2, double ext2, int* __restrict__ nrun,
-                                                      const int* __restrict__ roff, double2* __restrict__ r_c,
-                                                      double2* __restrict__ r_s, uint2* __restrict__ r_m) {
+                                                      const int* __restrict__ roff, double2* __restrict__ r_s,
+                                                      uint2* __restrict__ r_m) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= nloc) return;
     const int j0 = boff[t], j1 = boff[t + 1];
@@ -1107,8 +1109,7 @@ __global__ __launch_bounds__(kBlock) void k_run_build(const int* __restrict__ bo
                     r2 = fmax(r2, dx * dx + dy * dy);
                 }
                 const float rf = __double2float_ru(sqrt(r2) * 1.000001 + 1e-12);
-                r_c[o] = make_double2(cx, cy);
-                r_s[o] = make_double2(sx, sy);
+                r_s[o] = make_double2(sx, sy);   // (the centre is not stored: k_assoc_runs forms it by the same division, sx / k)
                 r_m[o] = make_uint2(__float_as_uint(rf), (unsigned)k | ((unsigned)(js - j0) << 16));
                 ++o;
             }
@@ -1175,10 +1176,10 @@ __device__ __forceinline__ int assoc_run(const GridView& g, const GridParams& gp
 #endif
 template <bool DEBUG, int HS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_RUNS_WPE : 4, HS == 128 ? 8 : 5)))
-void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, const double2* __restrict__ r_c,
+void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, const double2* __restrict__ r_s,
                   const double* __restrict__ rot, const GridParams* __restrict__ gpar, const int* __restrict__ plan, int nloc, int t_begin,
                   // ^ the fourteen dwords that arrive in scalar registers with the wave (kernel-argument preload)
-                  const double* __restrict__ x0, const double2* __restrict__ r_s, const uint2* __restrict__ r_m,
+                  const double* __restrict__ x0, const uint2* __restrict__ r_m,
                   const int* __restrict__ boff, const double2* __restrict__ bxy, GridView g, double thr, double thr2,
                   float thr_m, float eps, int* __restrict__ label, int* __restrict__ bloc, int* __restrict__ st_label,
                   unsigned short* __restrict__ st_k, double* __restrict__ st_sbx, double* __restrict__ st_sby,
@@ -1219,7 +1220,6 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
     auto at16 = [](const double2* __restrict__ base, unsigned idx) {
         return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + (idx << 4));
     };
-    const double2* __restrict__ rcp = r_c + R0;
     const double2* __restrict__ rsp = r_s + R0;
     const uint2* __restrict__ rmp = r_m + R0;
     // the pose's first 64 runs (lanes beyond the last run hold a copy of it and take no part)
@@ -1227,13 +1227,10 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
     uint2 m;
     {
         const unsigned i0 = min((unsigned)lane, nrun - 1u);
-        c = at16(rcp, i0);
-#ifndef ICM_EXP_NOSB
         sb = at16(rsp, i0);
-#else
-        sb = c;
-#endif
         m = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rmp) + (i0 << 3));
+        const double kd = (double)(m.y & 0xffffu);
+        c = make_double2(sb.x / kd, sb.y / kd);   // the circle's centre: the division k_run_build measured the radius against
     }
     for (int s = lane; s < kHash; s += kWave) {
         T.key[s] = kEmpty;
@@ -1340,9 +1337,10 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
         if (nent > kGroupCap) overflow = true;
         if (base + kWave < nrun) {   // (a scan with more than 64 runs)
             const unsigned in = min(base + (unsigned)kWave + (unsigned)lane, nrun - 1u);
-            c = at16(rcp, in);
             sb = at16(rsp, in);
             m = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(rmp) + (in << 3));
+            const double kd = (double)(m.y & 0xffffu);
+            c = make_double2(sb.x / kd, sb.y / kd);
         }
         __builtin_amdgcn_wave_barrier();
 #ifdef ICM_ASSOC_TS
