@@ -299,7 +299,7 @@ static inline int nblocks_threads(int64_t n) { return (int)((n + kBlock - 1) / k
 
 extern "C" {
 
-const char* icm_version(void) { return "icmslam-hip 0.4 (gfx950)"; }
+const char* icm_version(void) { return "icmslam-hip 0.5 (gfx950)"; }
 const char* icm_build_id(void) { return ICM_BUILD_ID; }
 
 int icm_flop_per_eval(void) { return ICM_FLOP_PER_EVAL; }
