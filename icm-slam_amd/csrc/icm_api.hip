@@ -86,7 +86,7 @@ struct icm_handle {
     DevBuf<int> nkept, boff, bk;
     DevBuf<double> bd, bx, by, pose_s2;
     DevBuf<unsigned long long> kmask, gh_kmask;   // the pre-filter's decisions: one bit per in-range beam (pass 1 -> pass 2)
-    DevBuf<double2> bxy, gh_bxy;   // the kept beams' body points once more, interleaved (k_assoc_group: one load per beam)
+    DevBuf<double2> bxy, gh_bxy;   // the kept beams' body points once more, interleaved (the beam-by-beam path: one load per beam)
     std::vector<int> h_boff;
     int64_t nnz = 0;
     // geometric runs of the kept beams (k_run_build, once per sequence): what phase A associates (k_assoc_runs)
@@ -134,7 +134,7 @@ struct icm_handle {
     DevBuf<int> rec_label;
     DevBuf<double> rec_s, rec_off, ms;   // [3][nrec], [3][nrec], [3][nsuper][L]
     int nchunks = 0, chunk_poses = 64, chunk_group = 1, nsuper = 0;
-    DevBuf<int> st_off;      // where each pose's staged entries start (k_assoc_group: packed area or sparse area)
+    DevBuf<int> st_off;      // where each pose's staged entries start (phase A: packed area or sparse area)
     StagingLayout stl;       // sizes of the staging area (staging_layout, icm_host.hpp: the one place that computes them)
     DevBuf<double> pre_x, pre_y;   // per-entry prefixes of the hierarchical path, one element per staging place (stl.prefix_stride)
     DevBuf<unsigned> pre_n;
@@ -186,7 +186,7 @@ struct icm_handle {
     int lact0 = 0;
     bool brute = false, debug = false, per_beam = false, assoc_kept = false;
     double thr2 = 0.0;  // largest s with sqrt(s) <= dist_thr
-    int hash_slots = 128;  // k_assoc_group's per-pose table; grows to 256 on overflow
+    int hash_slots = 128;  // phase A's per-pose label table; grows to 256 on overflow
     int solve_quad = -1;   // -1 automatic, 0 one lane per pose, 1 one quad per pose
     int form = 0;  // 0 moments (lane per pose), 1 per beam, 2 per entry (wave per pose)
     int *pin_i = nullptr, *pin_i_dev = nullptr;   // pinned host words and their device-side address
@@ -711,7 +711,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     HIPCHK(h, h->scan_tot.reserve(2 * ((size_t)nloc / kScanTile + 2)));
     HIPCHK(h, h->nent.reserve((size_t)nloc + 1)); HIPCHK(h, h->isnew.reserve((size_t)nloc + 1));
     HIPCHK(h, h->ent_off.reserve((size_t)nloc + 1)); HIPCHK(h, h->new_rank.reserve((size_t)nloc + 1));
-    HIPCHK(h, hipMemsetAsync(h->ent_off.p, 0, ((size_t)nloc + 1) * sizeof(int), h->stream));   // (no reservation plan yet: k_assoc_group)
+    HIPCHK(h, hipMemsetAsync(h->ent_off.p, 0, ((size_t)nloc + 1) * sizeof(int), h->stream));   // (no reservation plan yet: phase A)
     const size_t L = (size_t)h->cfg.L;
     HIPCHK(h, h->lm_off.reserve(L + 2)); HIPCHK(h, h->flags.reserve(32)); h->fl = h->flags.p; h->fl_parity = 0; h->fl_next_clean = false;   // [0..7] the sweep's flags and host words, [8..9] totals of a sweep without scan kernels
     HIPCHK(h, h->stats_own.reserve(3 * L + 8)); HIPCHK(h, h->off_sx.reserve(L)); HIPCHK(h, h->off_sy.reserve(L));
@@ -744,7 +744,7 @@ int icm_prefilter(icm_handle* h, int64_t* nnz_out) {
     h->ghost_n = 0;
     if (h->ghost_uploaded) {
         // filtrar_z of the ghost scan (pose t_begin - 1) into the ghost's own arrays, and room for its staged entries:
-        // a one-pose k_assoc_group with an all-zero reservation plan stages them at sparse0 = kWave
+        // a one-pose phase A launch with an all-zero reservation plan stages them at sparse0 = kWave
         const size_t Bz = (size_t)B, gst = (size_t)kWave + Bz + 512;
         HIPCHK(h, h->gh_nkept.reserve(2)); HIPCHK(h, h->gh_boff.reserve(2)); HIPCHK(h, h->gh_bk.reserve(Bz));
         HIPCHK(h, h->gh_bd.reserve(Bz)); HIPCHK(h, h->gh_bx.reserve(Bz)); HIPCHK(h, h->gh_by.reserve(Bz)); HIPCHK(h, h->gh_bxy.reserve(Bz)); HIPCHK(h, h->gh_kmask.reserve((Bz + kWave - 1) / kWave)); HIPCHK(h, h->gh_s2.reserve(3));

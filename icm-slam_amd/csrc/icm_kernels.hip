@@ -2,9 +2,12 @@
 //
 // Phase map:
 //   once      k_prefilter      filtrar_z for every scan            -> kept beams, CSR by pose
-//   phase A   k_assoc_group    project + gated nearest landmark + per-pose grouping: one
-//                              (pose, landmark) ENTRY per distinct label of the scan with
-//                              the count and the sums of the body / world points
+//             k_run_build      geometric runs of every scan's kept beams (bounding circle, count, sum)
+//   phase A   k_assoc_runs     project + gated nearest landmark BY RUNS (exact bounding-circle test, beam by beam
+//                              where it does not settle) + per-pose grouping: one (pose, landmark) ENTRY per
+//                              distinct label of the scan with the count and the sum of the body points
+//             k_assoc_group    the same beam by beam (until round 4 the hot kernel; now the cross-check form and
+//                              the grouping behind the brute-force search)
 //             k_neigh_table    per-cell 3x3 neighbourhood records of the search grid
 //             k_scan_*         entry offsets, ranks of poses that create a landmark
 //   phase B/D (default) hierarchical running sums, no sort:
@@ -26,7 +29,7 @@
 //             k_solve_* (wave per pose, per-beam / per-entry energy): cross-checks
 //   init      k_init_pass      the causal initialisation pass (one wave walks the sequence)
 //
-// Mapping: phase A one wavefront per pose (lanes over its kept beams), entry kernels one DPP
+// Mapping: phase A one wavefront per pose (lanes over its runs / its kept beams), entry kernels one DPP
 // row (16 lanes) per pose, landmark kernels one wavefront per landmark, solves one lane per
 // pose; 256-thread workgroups.  No MFMA: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
@@ -1171,11 +1174,8 @@ __device__ __forceinline__ int assoc_run(const GridView& g, const GridParams& gp
 
 // One wave per pose, lanes over its RUNS.  Same outputs as k_assoc_group (the pose's entries, one per distinct label, in
 // the order of the label table's slots, staged at the pose's reserved place): everything behind phase A is unchanged.
-#ifndef ICM_RUNS_WPE
-#define ICM_RUNS_WPE 7
-#endif
 template <bool DEBUG, int HS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? ICM_RUNS_WPE : 4, HS == 128 ? 8 : 5)))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HS == 128 ? 7 : 4, HS == 128 ? 8 : 5)))
 void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, const double2* __restrict__ r_s,
                   const double* __restrict__ rot, const GridParams* __restrict__ gpar, const int* __restrict__ plan, int nloc, int t_begin,
                   // ^ the fourteen dwords that arrive in scalar registers with the wave (kernel-argument preload)
@@ -1189,15 +1189,9 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
     constexpr int kHashShift = HS == 128 ? 25 : 24;
     __shared__ PoseTable<HS> tables[kWavesPerBlock];
     const int lane = lane_id();
-#ifdef ICM_EXP_XCD
-    // blocks b, b + 8, b + 16 ... run on one XCD (round-robin dispatch): give each XCD a contiguous range of poses
-    const int nbk = gridDim.x, per = (nbk + 7) >> 3;
-    const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (bid >= nbk) return;
-    const int tl = __builtin_amdgcn_readfirstlane(bid * kWavesPerBlock + wave_in_block());
-#else
+    // (one wave per pose, consecutive poses on consecutive workgroups: an XCD-contiguous order, eight resident waves and
+    // several poses per wave were all measured -- profiles/r05_assoc_runs_experiments.txt -- and lost or changed nothing)
     const int tl = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave_in_block());
-#endif
     if (tl >= nloc) return;
     ASSOC_TS(0);
     PoseTable<HS>& T = tables[wave_in_block()];
@@ -1364,10 +1358,8 @@ void k_assoc_runs(const double* __restrict__ x, const int* __restrict__ roff, co
             const unsigned q = (unsigned)(written + prefix_count(mask, lane));
             *reinterpret_cast<int*>(reinterpret_cast<char*>(st_label + sbase) + (q << 2)) = key;
             *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(st_k + sbase) + (q << 1)) = (unsigned short)T.cnt[s];
-#ifndef ICM_EXP_NOSTORE
             *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sbx + sbase) + (q << 3)) = T.sx[s];
             *reinterpret_cast<double*>(reinterpret_cast<char*>(st_sby + sbase) + (q << 3)) = T.sy[s];
-#endif
             isnew |= key == -1;
             if (DEBUG) T.owner[s] = q;
         }
