@@ -620,3 +620,63 @@ def init_pass(cfg, scans, u, odo, kept=None):
     y_raw, cnt_raw, lact_raw = y.copy(), state.cant_obs_i.copy(), state.landmarks_actuales
     yy = filtrar(state, y)
     return x, yy[:, :state.landmarks_actuales].copy(), state, c0, (y_raw, cnt_raw, lact_raw)
+
+
+# ---------------------------------------------------------------------------------------
+# Association by geometric runs (round 5): a CPU statement of the claim the HIP kernels
+# k_run_build / k_assoc_runs rest on, so that it can be checked against the reference's
+# literal per-beam rule (`associate` above = scripts/ICM_SLAM_tools.py:168-172) without a GPU.
+# ---------------------------------------------------------------------------------------
+RUN_CAP = 64
+
+
+def cut_runs(body_xy, dist_thr):
+    """Cut a scan's kept beams (n,2) body-frame points, in beam order, into runs: a new run starts where the next point
+    is farther than 0.35 dist_thr from the last one, farther than 0.5 dist_thr from the run's first point, or after
+    RUN_CAP beams.  Returns a list of (first, count)."""
+    gap2, ext2 = (0.35 * dist_thr) ** 2, (0.5 * dist_thr) ** 2
+    runs, js = [], 0
+    n = body_xy.shape[0]
+    for j in range(1, n + 1):
+        cut = j == n
+        if not cut:
+            g = body_xy[j] - body_xy[j - 1]
+            e = body_xy[j] - body_xy[js]
+            cut = g[0] * g[0] + g[1] * g[1] > gap2 or e[0] * e[0] + e[1] * e[1] > ext2 or j - js >= RUN_CAP
+        if cut:
+            runs.append((js, j - js))
+            js = j
+    return runs if n else []
+
+
+def run_decision(centre_w, radius, ref_map, lact, dist_thr):
+    """The bounding-circle test for one run: `centre_w` the run's centre projected with the pose (2,), `radius` a bound
+    on the distance of every beam of the run to the centre.  Candidates are the landmarks of the 3x3 cells (edge
+    dist_thr (1 + 1e-9), origin at the map's minimum) around the centre's cell, like the kernel's grid record.  Returns
+    the landmark index every beam of the run takes, or None when the test does not settle the run (crowded or distant
+    landmarks, gated-out beams, more than four candidates)."""
+    K = min(int(lact), ref_map.shape[1])
+    if K == 0:
+        return None
+    mx, my = ref_map[0, :K], ref_map[1, :K]
+    cell = dist_thr * (1.0 + 1e-9)
+    gx0, gy0 = mx.min(), my.min()
+    nx, ny = int(np.floor((mx.max() - gx0) / cell)) + 1, int(np.floor((my.max() - gy0) / cell)) + 1
+
+    def cidx(v, g0, n):
+        return np.clip(np.floor((v - g0) / cell), 0, n - 1).astype(np.int64)
+
+    cx, cy = int(cidx(centre_w[0], gx0, nx)), int(cidx(centre_w[1], gy0, ny))
+    lx, ly = cidx(mx, gx0, nx), cidx(my, gy0, ny)
+    cand = np.flatnonzero((np.abs(lx - cx) <= 1) & (np.abs(ly - cy) <= 1))
+    if cand.size == 0 or cand.size > 4:
+        return None
+    d = np.sqrt((mx[cand] - centre_w[0]) ** 2 + (my[cand] - centre_w[1]) ** 2)
+    order = np.argsort(d, kind="stable")
+    d1 = d[order[0]]
+    d2 = d[order[1]] if cand.size > 1 else np.inf
+    eps = 1e-4 * dist_thr
+    r = float(radius)
+    if d1 + r <= dist_thr - eps and (d1 + 2 * r) / cell <= 1.0 - 1e-4 and d2 - d1 >= 2 * r + eps:
+        return int(cand[order[0]])
+    return None

@@ -92,6 +92,37 @@ def test_runs_partition_the_kept_beams(which):
     eng.close()
 
 
+def test_device_runs_equal_the_oracle_cut_and_its_settled_share():
+    """k_run_build against the CPU statement of the cutting rule (oracle.cut_runs) on data_IJAC2018: the same runs, beam
+    for beam; and the device's count of runs that went beam by beam in sweep 1 equals the number of runs the oracle's
+    bounding-circle test (oracle.run_decision) does not settle."""
+    from oracle import icm_oracle as o
+    eng, map0, x_init, x0 = _engine_dataset()
+    off, bk, d, bx, by = eng.kept_beams()
+    roff, c, sb, r, k, f = eng.runs()
+    mine = [[(int(f[q]), int(k[q])) for q in range(roff[t], roff[t + 1])] for t in range(len(off) - 1)]
+    unsettled = 0
+    for t in range(len(off) - 1):
+        body = np.stack((bx[off[t]:off[t + 1]], by[off[t]:off[t + 1]]), axis=1)
+        want = o.cut_runs(body, 1.0)
+        assert mine[t] == want, "runs of scan %d" % t
+        pose = x0 if t == 0 else x_init[:, t]
+        for first, cnt in want:
+            b = body[first:first + cnt]
+            cc = b.sum(axis=0) / cnt
+            rr = np.sqrt(((b - cc) ** 2).sum(axis=1)).max() * 1.000001 + 1e-12
+            if o.run_decision(o.project_beams(pose, cc[None, :])[0], rr, map0, map0.shape[1], 1.0) is None:
+                unsettled += 1
+    eng.set_assoc_form("runs")
+    eng.set_state(map0, x_init, x0)
+    before = eng.run_counts()[1]
+    eng.sweep_device("sequential")
+    bbb = eng.run_counts()[1] - before
+    print("data_IJAC2018: %d runs equal the oracle's cut; beam by beam: device %d, oracle's rule %d" % (len(k), bbb, unsettled))
+    assert bbb == unsettled
+    eng.close()
+
+
 def _sweep_both_forms(eng, map0, x0_, xstart, sweeps=2, schedule="redblack"):
     out = {}
     for form in ("beams", "runs"):
